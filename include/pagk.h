@@ -1,0 +1,175 @@
+/*
+ * pagk.h -- C ABI of the MI355X-native pyramidal patch-based KLT refinement.
+ *
+ * This is the drop-in boundary for ONE path of the reference tracker: the body of
+ * PatchMatch::OpticalFlowMultiLevel() (reference src/patch_match.cpp:79-142) and
+ * everything it calls.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Every entry point cites the reference interface it replaces.  All buffers are
+ * caller-owned; the library owns only its pagk_ctx (device buffers, stream).
+ *
+ * Conventions
+ *   - points are interleaved (x, y) float32 pairs, n of them  (cv::Point2f layout)
+ *   - affine is n x 4 float32, row-major 2x2 per feature      (cv::Mat CV_32F 2x2,
+ *     reference src/gyro_aided_tracker.cpp:166-168)
+ *   - status bytes are 0 / 1                                   (std::vector<uchar>)
+ *   - return value: 0 = PAGK_OK, negative = error (never throws, never aborts)
+ */
+#ifndef PAGK_H
+#define PAGK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAGK_VERSION 100 /* 0.1.0 */
+
+#define PAGK_MAX_PYRAMIDS 8
+#define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
+
+enum {
+    PAGK_OK = 0,
+    PAGK_E_ARG = -1,         /* null pointer / out-of-range parameter                     */
+    PAGK_E_HIP = -2,         /* a HIP runtime call failed (see pagk_last_error)           */
+    PAGK_E_NOMEM = -3,       /* device or host allocation failed                          */
+    PAGK_E_UNSUPPORTED = -4, /* inverse-compositional mode (reference: "not support yet") */
+    PAGK_E_NODEVICE = -5     /* no HIP device / HIP library could not initialise          */
+};
+
+/* 8-bit single-channel image view.  Mirrors the fields of cv::Mat (CV_8UC1) the
+ * reference reads: data, cols, rows, step (src/patch_match.cpp:396-403). */
+typedef struct pagk_image {
+    const uint8_t *data;
+    int32_t width;  /* cv::Mat::cols */
+    int32_t height; /* cv::Mat::rows */
+    int64_t step;   /* cv::Mat::step, bytes per row, >= width */
+} pagk_image;
+
+/* Arguments of PatchMatch::PatchMatch (include/patch_match.h:44-49) plus the
+ * constants its constructor hard-codes (src/patch_match.cpp:48-57) and the camera
+ * model DistortPoints() reads from the tracker (src/patch_match.cpp:409-416,
+ * src/utils.cpp:49-76). Fill with pagk_params_default() and override. */
+typedef struct pagk_params {
+    int32_t half_patch; /* halfPatchSize_  (reference apps: 5; BASELINE: 10)             */
+    int32_t iterations; /* iterations_     (reference call site: 10; BASELINE: 30)       */
+    int32_t pyramids;   /* pyramids_       (reference call site: 3)                      */
+    uint8_t has_gyro_predict_initial; /* bHasGyroPredictInitial_: 0 => pt_init ignored   */
+    uint8_t inverse;                  /* bInverse_: must be 0 (PAGK_E_UNSUPPORTED)        */
+    uint8_t consider_illumination;    /* bConsiderIllumination_                           */
+    uint8_t consider_affine;          /* bConsiderAffineDeformation_                      */
+    uint8_t regularization_penalty;   /* bRegularizationPenalty_                          */
+    uint8_t calculate_ncc;            /* bCalculateNCC_                                   */
+    uint8_t reserved0[2];
+    float lambda;            /* mLambda      = 1.0f  (:48) */
+    float alpha;             /* mAlpha       = 0.5f  (:49) */
+    int32_t max_distance;    /* mMaxDistance = 25    (:50) */
+    float inv_log_max_dist;  /* mInvLogMaxDist (:51); 0 => computed by the library       */
+    /* camera model used only by the distortion epilogue */
+    float fx, fy, cx, cy;    /* mK(0,0), mK(1,1), mK(0,2), mK(1,2)                        */
+    float dist_coef[5];      /* k1 k2 p1 p2 k3                                            */
+    int32_t n_dist_coef;     /* 4 or 5 (mDistCoef.total()); k3 ignored unless 5           */
+} pagk_params;
+
+/* Outputs == the six vectors PatchMatch::SetMatcher fills on the tracker
+ * (src/patch_match.cpp:370-388, include/gyro_aided_tracker.h:214-219) plus an
+ * optional diagnostic. Any pointer except pt_un/status may be NULL. */
+typedef struct pagk_outputs {
+    float *pt_un;      /* n x 2  mvPtPredictAfterPatchMatchedUn                           */
+    float *pt_dist;    /* n x 2  mvPtPredictAfterPatchMatched (distorted)                 */
+    uint8_t *status;   /* n      mvStatusAfterPatchMatched                                */
+    double *pix_err;   /* n      mvPixelErrorsOfPatchMatched                              */
+    double *dist_pred; /* n      mvDistanceBetweenPredictedAndPatchMatched                */
+    float *ncc;        /* n      mvNccAfterPatchMatched                                   */
+    int32_t *iters;    /* n      diagnostic: Gauss-Newton iterations executed, summed
+                                 over levels (not in the reference)                       */
+} pagk_outputs;
+
+typedef struct pagk_ctx pagk_ctx;
+
+/* ---- library / context ------------------------------------------------------ */
+int pagk_version(void);
+const char *pagk_strerror(int code);
+/* Text of the last HIP failure on this context (empty string if none). */
+const char *pagk_last_error(const pagk_ctx *ctx);
+
+/* Defaults == reference call site src/gyro_aided_tracker.cpp:276-282 with
+ * eType GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION
+ * (:402-408): h=5, 10 iterations, 3 levels, gyro init, illumination + affine. */
+void pagk_params_default(pagk_params *p);
+/* mInvLogMaxDist exactly as src/patch_match.cpp:51 computes it. */
+float pagk_inv_log_max_dist(float alpha, int32_t max_distance);
+
+/* One context per host thread / GPU (reference: one PatchMatch per tracker, not
+ * re-entrant because of the shared mLevel, src/patch_match.cpp:99). */
+int pagk_create(pagk_ctx **out, int device);
+void pagk_destroy(pagk_ctx *ctx);
+
+/* ---- the hot path, host buffers (drop-in for OpticalFlowMultiLevel) -------- */
+/* Replaces PatchMatch::OpticalFlowMultiLevel() src/patch_match.cpp:79-142:
+ * CreatePyramids (:61-76) + per-level per-feature GN loop (:167-367) +
+ * DistortPoints (:409-416) + SetMatcher (:370-388).  Synchronous.
+ *   pt_ref_un  = mvKeysRefUn[i].pt        pt_init_un = mvPtPredictUn[i]
+ *   affine     = mvAffineDeformationMatrix[i] (may be NULL iff !consider_affine)
+ *   status_in  = mvStatus[i] snapshot (mvGyroPredictStatus, :58)                */
+int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref,
+               const pagk_image *cur, int32_t n, const float *pt_ref_un,
+               const float *pt_init_un, const float *affine, const uint8_t *status_in,
+               const pagk_outputs *out);
+
+/* Same, but with caller-built pyramids (levels[0] = full resolution), so a host
+ * that links real OpenCV can hand over cv::resize output (:69-70) verbatim. */
+int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels,
+                   const pagk_image *ref_levels, const pagk_image *cur_levels, int32_t n,
+                   const float *pt_ref_un, const float *pt_init_un, const float *affine,
+                   const uint8_t *status_in, const pagk_outputs *out);
+
+/* ---- the hot path, device-resident (streams of frame pairs, benchmarks) ---- */
+/* Upload a frame into one of the context's frame slots and build its pyramid on
+ * the device (CreatePyramids :61-76). In a sequence, cur of pair t is ref of pair
+ * t+1, so each frame is uploaded once. slot in [0, 4). */
+int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids);
+/* Same for an image that already lives in device memory (d_data: device pointer,
+ * rows of `step` bytes). Asynchronous on the context stream. */
+int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width,
+                          int32_t height, int64_t step, int32_t pyramids);
+/* Copy one pyramid level of a slot back to the host (tests: pyramid parity). */
+int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst,
+                              int32_t *width, int32_t *height);
+
+/* Track with every per-feature array in DEVICE memory (all pointers are device
+ * pointers; same layouts as pagk_track). Asynchronous on the context stream;
+ * call pagk_sync before reading results on the host. */
+int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref,
+                      int32_t slot_cur, int32_t n, const float *d_pt_ref_un,
+                      const float *d_pt_init_un, const float *d_affine,
+                      const uint8_t *d_status_in, const pagk_outputs *d_out);
+int pagk_sync(pagk_ctx *ctx);
+/* Use an external HIP stream (e.g. torch's current stream) instead of the
+ * context's own; pass NULL to restore. */
+int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
+
+/* Kernel selection: 0 = default (wave-slot kernel), 1 = reference-shaped
+ * one-thread-per-feature kernel (debug / cross-check). */
+int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
+
+/* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,
+ * measured with HIP events on the stream the kernels ran on. Synchronises. */
+int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms);
+
+/* ---- producer / consumer rows next to the path ----------------------------- */
+/* Tracker-side post-filter, GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined
+ * Step 3 (src/gyro_aided_tracker.cpp:289-341): thresholds from the mean pixel
+ * error, final inlier mask, survivors' points copied into pt_predict(_un).
+ * Host-side; returns the number of survivors (>= 0) or a negative error. */
+int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
+                     const double *pix_err, const double *dist_pred, const float *pt_pm,
+                     const float *pt_pm_un, uint8_t *status_out, float *pt_predict,
+                     float *pt_predict_un);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGK_H */

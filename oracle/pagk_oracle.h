@@ -1,0 +1,72 @@
+/*
+ * pagk_oracle.h -- CPU oracle for the PatchMatch hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * only as the checker / the timed CPU baseline.  The product (libpagk_hip.so) never
+ * links, loads or falls back to this code.
+ *
+ * PARITY UNPINNED: the reference (C++ on OpenCV + Eigen + glog) cannot be built in
+ * this environment and ships no tests or golden vectors, so this restatement could
+ * not be checked against reference outputs.  It follows the reference's own source
+ * type-for-type (citations on every function); the arithmetic that lives in absent
+ * third-party code is restated from the published algorithms and listed in
+ * oracle/README.md (cv::resize 2x decimation, Eigen 3.3 fixed-size LLT / triangular
+ * solves / norm reduction order, libm log).
+ */
+#ifndef PAGK_ORACLE_H
+#define PAGK_ORACLE_H
+
+#include "../include/pagk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::resize(src, dst, Size(cols*0.5, rows*0.5)) for an even-sized 8UC1 image
+ * (reference src/patch_match.cpp:69-70).  dst is (w/2) x (h/2), contiguous. */
+int pagk_oracle_pyr_down(const uint8_t *src, int32_t w, int32_t h, int64_t step, uint8_t *dst);
+
+/* PatchMatch::OpticalFlowMultiLevel (src/patch_match.cpp:79-142) on host buffers;
+ * same arguments as pagk_track.  nthreads stripes features over pthreads the way
+ * cv::parallel_for_ does (:103); nthreads <= 0 means one thread. */
+int pagk_oracle_track(const pagk_params *params, const pagk_image *ref, const pagk_image *cur,
+                      int32_t n, const float *pt_ref_un, const float *pt_init_un,
+                      const float *affine, const uint8_t *status_in, const pagk_outputs *out,
+                      int32_t nthreads);
+
+/* Same with caller-built pyramids (same arguments as pagk_track_pyr). */
+int pagk_oracle_track_pyr(const pagk_params *params, int32_t n_levels,
+                          const pagk_image *ref_levels, const pagk_image *cur_levels, int32_t n,
+                          const float *pt_ref_un, const float *pt_init_un, const float *affine,
+                          const uint8_t *status_in, const pagk_outputs *out, int32_t nthreads);
+
+/* GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined Step 3
+ * (src/gyro_aided_tracker.cpp:289-341); same arguments as pagk_post_filter. */
+int pagk_oracle_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
+                            const double *pix_err, const double *dist_pred, const float *pt_pm,
+                            const float *pt_pm_un, uint8_t *status_out, float *pt_predict,
+                            float *pt_predict_un);
+
+/* GyroAidedTracker::GyroPredictFeatures + GyroPredictOnePixel, PIXEL_AWARE_PREDICTION
+ * (src/gyro_aided_tracker.cpp:118-185,194-231).  KRKinv: 3x3 row-major float
+ * (mKRKinv), r3: third row of Rcl (mr31 mr32 mr33).  Outputs: pt_predict_un,
+ * pt_predict (distorted), status (n), affine (n x 4; untouched where status 0). */
+int pagk_oracle_gyro_predict(const pagk_params *cam, int32_t width, int32_t height, int32_t half_patch,
+                             const float *KRKinv, const float *r3, int32_t n, const float *pt_ref_un,
+                             float *pt_predict_un, float *pt_predict, uint8_t *status, float *affine);
+
+/* The shared software log (see oracle/README.md, "libm log"). */
+double pagk_oracle_log(double x);
+/* mInvLogMaxDist (src/patch_match.cpp:51). */
+float pagk_oracle_inv_log_max_dist(float alpha, int32_t max_distance);
+
+/* 4x4 LLT + solve + norm exactly as the GN loop uses them (src/patch_match.cpp:319,343);
+ * exposed so the tests can pin the restatement's own corner cases.
+ * H: 16 doubles row-major (only the lower triangle is read); returns ||x||. */
+double pagk_oracle_llt_solve4(const double *H, const double *b, double *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

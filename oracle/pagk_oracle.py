@@ -1,0 +1,129 @@
+"""ctypes loader for the CPU oracle (oracle/libpagk_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, nowhere else.  The product never loads it.
+PARITY UNPINNED: see pagk_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pixel_aware_gyro_aided_klt_feature_tracker_amd.capi import (Image, Outputs, Params, alloc_outputs, image_view,
+                                                                 outputs_struct)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpagk_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "pagk_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", HERE, "libpagk_oracle.so"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, P = C.c_void_p, C.c_int32, C.POINTER
+        lib.pagk_oracle_pyr_down.restype = C.c_int
+        lib.pagk_oracle_pyr_down.argtypes = [vp, i32, i32, C.c_int64, vp]
+        lib.pagk_oracle_track.restype = C.c_int
+        lib.pagk_oracle_track.argtypes = [P(Params), P(Image), P(Image), i32, vp, vp, vp, vp, P(Outputs), i32]
+        lib.pagk_oracle_track_pyr.restype = C.c_int
+        lib.pagk_oracle_track_pyr.argtypes = [P(Params), i32, P(Image), P(Image), i32, vp, vp, vp, vp, P(Outputs), i32]
+        lib.pagk_oracle_post_filter.restype = C.c_int
+        lib.pagk_oracle_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.pagk_oracle_gyro_predict.restype = C.c_int
+        lib.pagk_oracle_gyro_predict.argtypes = [P(Params), i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+        lib.pagk_oracle_log.restype = C.c_double
+        lib.pagk_oracle_log.argtypes = [C.c_double]
+        lib.pagk_oracle_inv_log_max_dist.restype = C.c_float
+        lib.pagk_oracle_inv_log_max_dist.argtypes = [C.c_float, i32]
+        lib.pagk_oracle_llt_solve4.restype = C.c_double
+        lib.pagk_oracle_llt_solve4.argtypes = [vp, vp, vp]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def pyr_down(img: np.ndarray) -> np.ndarray:
+    h, w = img.shape
+    out = np.zeros((h // 2, w // 2), np.uint8)
+    rc = load().pagk_oracle_pyr_down(img.ctypes.data, w, h, img.strides[0], out.ctypes.data)
+    if rc:
+        raise RuntimeError(f"pagk_oracle_pyr_down: {rc}")
+    return out
+
+
+def track(params: Params, img_ref, img_cur, pt_ref, pt_init, affine, status_in, nthreads: int = 1, out=None):
+    n = int(pt_ref.shape[0])
+    out = out if out is not None else alloc_outputs(n)
+    ir, ic = image_view(img_ref), image_view(img_cur)
+    o = outputs_struct(out)
+    rc = load().pagk_oracle_track(C.byref(params), C.byref(ir), C.byref(ic), n, _p(pt_ref), _p(pt_init), _p(affine),
+                                  _p(status_in), C.byref(o), nthreads)
+    if rc:
+        raise RuntimeError(f"pagk_oracle_track: {rc}")
+    return out
+
+
+def track_pyr(params: Params, ref_levels, cur_levels, pt_ref, pt_init, affine, status_in, nthreads: int = 1):
+    n = int(pt_ref.shape[0])
+    out = alloc_outputs(n)
+    L = len(ref_levels)
+    r = (Image * L)(*[image_view(a) for a in ref_levels])
+    c = (Image * L)(*[image_view(a) for a in cur_levels])
+    o = outputs_struct(out)
+    rc = load().pagk_oracle_track_pyr(C.byref(params), L, r, c, n, _p(pt_ref), _p(pt_init), _p(affine),
+                                      _p(status_in), C.byref(o), nthreads)
+    if rc:
+        raise RuntimeError(f"pagk_oracle_track_pyr: {rc}")
+    return out
+
+
+def post_filter(half_patch: int, status_pm, pix_err, dist_pred, pt_pm, pt_pm_un):
+    n = int(status_pm.shape[0])
+    status = np.zeros(max(n, 1), np.uint8)
+    pp = np.zeros((max(n, 1), 2), np.float32)
+    ppu = np.zeros((max(n, 1), 2), np.float32)
+    rc = load().pagk_oracle_post_filter(n, half_patch, _p(status_pm), _p(pix_err), _p(dist_pred), _p(pt_pm),
+                                        _p(pt_pm_un), _p(status), _p(pp), _p(ppu))
+    if rc < 0:
+        raise RuntimeError(f"pagk_oracle_post_filter: {rc}")
+    return rc, status[:n], pp[:n], ppu[:n]
+
+
+def gyro_predict(cam_params: Params, width, height, half_patch, KRKinv, r3, pt_ref):
+    n = int(pt_ref.shape[0])
+    KRKinv = np.ascontiguousarray(KRKinv, np.float32)
+    r3 = np.ascontiguousarray(r3, np.float32)
+    pu = np.zeros((n, 2), np.float32)
+    pd = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    A = np.zeros((n, 4), np.float32)
+    rc = load().pagk_oracle_gyro_predict(C.byref(cam_params), width, height, half_patch, KRKinv.ctypes.data,
+                                         r3.ctypes.data, n, pt_ref.ctypes.data, pu.ctypes.data, pd.ctypes.data,
+                                         st.ctypes.data, A.ctypes.data)
+    if rc < 0:
+        raise RuntimeError(f"pagk_oracle_gyro_predict: {rc}")
+    return pu, pd, st, A
+
+
+def llt_solve4(H: np.ndarray, b: np.ndarray):
+    H = np.ascontiguousarray(H, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(4, np.float64)
+    nrm = load().pagk_oracle_llt_solve4(H.ctypes.data, b.ctypes.data, x.ctypes.data)
+    return x, nrm

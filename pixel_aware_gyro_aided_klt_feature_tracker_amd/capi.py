@@ -1,0 +1,280 @@
+"""ctypes binding of include/pagk.h (libpagk_hip.so, built by __graft_entry__.build()).
+
+This is the only way Python reaches the product.  There is no CPU fallback: if the
+shared library is missing, or no HIP device can be opened, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libpagk_hip.so")
+
+PAGK_OK = 0
+PAGK_E_ARG = -1
+PAGK_E_HIP = -2
+PAGK_E_NOMEM = -3
+PAGK_E_UNSUPPORTED = -4
+PAGK_E_NODEVICE = -5
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("step", C.c_int64)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("half_patch", C.c_int32), ("iterations", C.c_int32), ("pyramids", C.c_int32),
+        ("has_gyro_predict_initial", C.c_uint8), ("inverse", C.c_uint8),
+        ("consider_illumination", C.c_uint8), ("consider_affine", C.c_uint8),
+        ("regularization_penalty", C.c_uint8), ("calculate_ncc", C.c_uint8),
+        ("reserved0", C.c_uint8 * 2),
+        ("lambda_", C.c_float), ("alpha", C.c_float), ("max_distance", C.c_int32),
+        ("inv_log_max_dist", C.c_float),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("dist_coef", C.c_float * 5), ("n_dist_coef", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("pt_un", C.c_void_p), ("pt_dist", C.c_void_p), ("status", C.c_void_p),
+                ("pix_err", C.c_void_p), ("dist_pred", C.c_void_p), ("ncc", C.c_void_p),
+                ("iters", C.c_void_p)]
+
+
+def make_params(*, half_patch=5, iterations=10, pyramids=3, has_gyro=True, illumination=True,
+                affine=True, penalty=False, ncc=False, inverse=False, camera=None) -> Params:
+    """pagk_params_default() (reference call site src/gyro_aided_tracker.cpp:276-282)
+    with overrides.  `camera` is a synth.Camera or None."""
+    p = Params()
+    p.half_patch, p.iterations, p.pyramids = half_patch, iterations, pyramids
+    p.has_gyro_predict_initial = int(has_gyro)
+    p.inverse = int(inverse)
+    p.consider_illumination = int(illumination)
+    p.consider_affine = int(affine)
+    p.regularization_penalty = int(penalty)
+    p.calculate_ncc = int(ncc)
+    p.lambda_, p.alpha, p.max_distance = 1.0, 0.5, 25
+    p.inv_log_max_dist = 0.0
+    if camera is not None:
+        p.fx, p.fy, p.cx, p.cy = camera.fx, camera.fy, camera.cx, camera.cy
+        for i, v in enumerate(camera.dist[:5]):
+            p.dist_coef[i] = v
+        p.n_dist_coef = max(4, len(camera.dist))
+    else:
+        p.fx = p.fy = 1.0
+        p.n_dist_coef = 4
+    return p
+
+
+def image_view(a: np.ndarray) -> Image:
+    assert a.dtype == np.uint8 and a.ndim == 2 and a.strides[1] == 1
+    return Image(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0])
+
+
+def alloc_outputs(n: int, with_iters: bool = True) -> dict:
+    nn = max(n, 1)
+    d = dict(pt_un=np.zeros((nn, 2), np.float32), pt_dist=np.zeros((nn, 2), np.float32),
+             status=np.zeros(nn, np.uint8), pix_err=np.zeros(nn, np.float64),
+             dist_pred=np.zeros(nn, np.float64), ncc=np.zeros(nn, np.float32))
+    if with_iters:
+        d["iters"] = np.zeros(nn, np.int32)
+    return d
+
+
+def outputs_struct(d: dict) -> Outputs:
+    o = Outputs()
+    for k in ("pt_un", "pt_dist", "status", "pix_err", "dist_pred", "ncc", "iters"):
+        v = d.get(k)
+        if v is None:
+            setattr(o, k, None)
+        elif isinstance(v, np.ndarray):
+            setattr(o, k, v.ctypes.data)
+        else:  # torch tensor (device pointer)
+            setattr(o, k, v.data_ptr())
+    return o
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+_P = C.POINTER
+_lib = None
+
+
+def declare(lib) -> None:
+    """argtypes/restype for every symbol include/pagk.h declares."""
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.pagk_version.restype = C.c_int
+    lib.pagk_version.argtypes = []
+    lib.pagk_strerror.restype = C.c_char_p
+    lib.pagk_strerror.argtypes = [C.c_int]
+    lib.pagk_last_error.restype = C.c_char_p
+    lib.pagk_last_error.argtypes = [vp]
+    lib.pagk_params_default.restype = None
+    lib.pagk_params_default.argtypes = [_P(Params)]
+    lib.pagk_inv_log_max_dist.restype = C.c_float
+    lib.pagk_inv_log_max_dist.argtypes = [C.c_float, i32]
+    lib.pagk_create.restype = C.c_int
+    lib.pagk_create.argtypes = [_P(vp), C.c_int]
+    lib.pagk_destroy.restype = None
+    lib.pagk_destroy.argtypes = [vp]
+    lib.pagk_track.restype = C.c_int
+    lib.pagk_track.argtypes = [vp, _P(Params), _P(Image), _P(Image), i32, vp, vp, vp, vp, _P(Outputs)]
+    lib.pagk_track_pyr.restype = C.c_int
+    lib.pagk_track_pyr.argtypes = [vp, _P(Params), i32, _P(Image), _P(Image), i32, vp, vp, vp, vp, _P(Outputs)]
+    lib.pagk_frame_upload.restype = C.c_int
+    lib.pagk_frame_upload.argtypes = [vp, i32, _P(Image), i32]
+    lib.pagk_frame_set_device.restype = C.c_int
+    lib.pagk_frame_set_device.argtypes = [vp, i32, vp, i32, i32, C.c_int64, i32]
+    lib.pagk_frame_download_level.restype = C.c_int
+    lib.pagk_frame_download_level.argtypes = [vp, i32, i32, vp, _P(i32), _P(i32)]
+    lib.pagk_track_device.restype = C.c_int
+    lib.pagk_track_device.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs)]
+    lib.pagk_sync.restype = C.c_int
+    lib.pagk_sync.argtypes = [vp]
+    lib.pagk_set_stream.restype = C.c_int
+    lib.pagk_set_stream.argtypes = [vp, vp]
+    lib.pagk_set_kernel.restype = C.c_int
+    lib.pagk_set_kernel.argtypes = [vp, i32]
+    lib.pagk_last_kernel_ms.restype = C.c_int
+    lib.pagk_last_kernel_ms.argtypes = [vp, _P(C.c_float), _P(C.c_float)]
+    lib.pagk_post_filter.restype = C.c_int
+    lib.pagk_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+
+
+EXPORTED_SYMBOLS = [
+    "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
+    "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
+    "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
+    "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter",
+]
+
+
+def load():
+    """Load libpagk_hip.so.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The HIP path is the product; there is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        declare(lib)
+        _lib = lib
+    return _lib
+
+
+class PagkError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        msg = load().pagk_strerror(code).decode()
+        super().__init__(f"{where}: {msg} ({code}){': ' + detail if detail else ''}")
+
+
+class Context:
+    """pagk_ctx owner.  One per GPU / host thread."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.pagk_create(C.byref(h), device)
+        if rc != PAGK_OK:
+            raise PagkError(rc, "pagk_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pagk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, where: str):
+        if rc != PAGK_OK:
+            raise PagkError(rc, where, self.lib.pagk_last_error(self.h).decode())
+
+    # host-buffer path ------------------------------------------------------------------
+    def track(self, params: Params, img_ref, img_cur, pt_ref, pt_init, affine, status_in, out: dict | None = None):
+        n = int(pt_ref.shape[0])
+        out = out if out is not None else alloc_outputs(n)
+        ir, ic = image_view(img_ref), image_view(img_cur)
+        o = outputs_struct(out)
+        self._check(self.lib.pagk_track(self.h, C.byref(params), C.byref(ir), C.byref(ic), n, _ptr(pt_ref),
+                                        _ptr(pt_init), _ptr(affine), _ptr(status_in), C.byref(o)), "pagk_track")
+        return out
+
+    def track_pyr(self, params: Params, ref_levels, cur_levels, pt_ref, pt_init, affine, status_in, out=None):
+        n = int(pt_ref.shape[0])
+        out = out if out is not None else alloc_outputs(n)
+        L = len(ref_levels)
+        r = (Image * L)(*[image_view(a) for a in ref_levels])
+        c = (Image * L)(*[image_view(a) for a in cur_levels])
+        o = outputs_struct(out)
+        self._check(self.lib.pagk_track_pyr(self.h, C.byref(params), L, r, c, n, _ptr(pt_ref), _ptr(pt_init),
+                                            _ptr(affine), _ptr(status_in), C.byref(o)), "pagk_track_pyr")
+        return out
+
+    # device-resident path --------------------------------------------------------------
+    def frame_upload(self, slot: int, img: np.ndarray, pyramids: int):
+        iv = image_view(img)
+        self._check(self.lib.pagk_frame_upload(self.h, slot, C.byref(iv), pyramids), "pagk_frame_upload")
+
+    def frame_set_device(self, slot: int, d_ptr: int, width: int, height: int, step: int, pyramids: int):
+        self._check(self.lib.pagk_frame_set_device(self.h, slot, d_ptr, width, height, step, pyramids),
+                    "pagk_frame_set_device")
+
+    def frame_download_level(self, slot: int, level: int, width: int, height: int) -> np.ndarray:
+        w, h = C.c_int32(0), C.c_int32(0)
+        buf = np.zeros((height >> level, width >> level), np.uint8)
+        self._check(self.lib.pagk_frame_download_level(self.h, slot, level, buf.ctypes.data, C.byref(w), C.byref(h)),
+                    "pagk_frame_download_level")
+        assert (h.value, w.value) == buf.shape
+        return buf
+
+    def track_device(self, params: Params, slot_ref: int, slot_cur: int, n: int, d_pt_ref, d_pt_init, d_affine,
+                     d_status, d_out: dict):
+        o = outputs_struct(d_out)
+        self._check(self.lib.pagk_track_device(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
+                                               _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o)),
+                    "pagk_track_device")
+
+    def sync(self):
+        self._check(self.lib.pagk_sync(self.h), "pagk_sync")
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.lib.pagk_set_stream(self.h, stream_ptr), "pagk_set_stream")
+
+    def set_kernel(self, which: int):
+        self._check(self.lib.pagk_set_kernel(self.h, which), "pagk_set_kernel")
+
+    def last_kernel_ms(self):
+        t, p = C.c_float(0), C.c_float(0)
+        self._check(self.lib.pagk_last_kernel_ms(self.h, C.byref(t), C.byref(p)), "pagk_last_kernel_ms")
+        return t.value, p.value
+
+
+def post_filter(half_patch: int, status_pm, pix_err, dist_pred, pt_pm, pt_pm_un):
+    """pagk_post_filter: the tracker-side inlier mask (reference src/gyro_aided_tracker.cpp:289-341)."""
+    lib = load()
+    n = int(status_pm.shape[0])
+    status = np.zeros(max(n, 1), np.uint8)
+    pp = np.zeros((max(n, 1), 2), np.float32)
+    ppu = np.zeros((max(n, 1), 2), np.float32)
+    rc = lib.pagk_post_filter(n, half_patch, _ptr(status_pm), _ptr(pix_err), _ptr(dist_pred), _ptr(pt_pm),
+                              _ptr(pt_pm_un), _ptr(status), _ptr(pp), _ptr(ppu))
+    if rc < 0:
+        raise PagkError(rc, "pagk_post_filter")
+    return rc, status[:n], pp[:n], ppu[:n]
