@@ -83,23 +83,28 @@ typedef struct {
 
 static inline float tap(const level_t *im, int64_t off)
 {
-    /* uchar -> int -> float, as in  a * data[0]  (:402) */
-    return (off >= 0 && off < im->size) ? (float)(int)im->data[off] : 0.0f;
+    /* uchar -> int -> float, as in  a * data[0]  (:402).  Row padding (columns in
+     * [cols, step) of a non-continuous Mat) is defined as 0 as well: the product copies
+     * only the `cols` valid bytes of each row to the device. */
+    if (off < 0 || off >= im->size) return 0.0f;
+    if (im->step != im->cols && (off % im->step) >= im->cols) return 0.0f;
+    return (float)(int)im->data[off];
 }
 
 /* PatchMatch::GetPixelValue, src/patch_match.cpp:391-406 (the member, not the free
  * function of include/utils.h:32-46). */
 static inline float get_pixel_value(const level_t *img, float x, float y)
 {
-    if (x < 0) x = 0;
-    if (y < 0) y = 0;
+    /* `if (x < 0) x = 0;` written so that a NaN coordinate also becomes 0: int(NaN) is
+     * undefined in the reference, and NaN cannot reach this point from finite inputs (a
+     * NaN update breaks at :322 before being applied).  Identical for every non-NaN x
+     * (-0.0 stays -0.0 in both forms). */
+    if (!(x >= 0)) x = 0;
+    if (!(y >= 0)) y = 0;
     if (x >= img->cols) x = img->cols - 1;
     if (y >= img->rows) y = img->rows - 1;
-    /* int(NaN) is undefined in the reference; NaN coordinates cannot reach this point
-     * from finite inputs (a NaN update breaks at :322 before being applied).  Define
-     * NaN -> 0 so that oracle and device agree on garbage-in. */
-    int ix = (x == x) ? (int)x : 0;
-    int iy = (y == y) ? (int)y : 0;
+    int ix = (int)x;
+    int iy = (int)y;
     int64_t off = (int64_t)iy * img->step + ix;
     float xx = x - floorf(x), yy = y - floorf(y);
     float a = 1.0f - xx, b = 1.0f - yy;

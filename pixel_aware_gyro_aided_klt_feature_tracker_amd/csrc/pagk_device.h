@@ -1,0 +1,269 @@
+// pagk_device.h -- device-side building blocks of the PatchMatch hot path (gfx950).
+//
+// Everything here must round exactly like the reference's baseline x86-64 build: one
+// IEEE rounding per operation.  The translation unit is compiled with
+// -ffp-contract=off (no FMA contraction), f32 denormals preserved (hipcc default on
+// gfx9), correctly rounded f32/f64 divide and sqrt (hipcc defaults).
+//
+// file:line citations are relative to the reference checkout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pagk {
+
+constexpr int kMaxLevels = 8;
+
+// One pyramid level as the kernels see it: the "quad image".  quad[r*cols + c] packs the
+// four bilinear taps of pixel (r, c) exactly as PatchMatch::GetPixelValue addresses them
+// (src/patch_match.cpp:399-403): byte0 = data[off], byte1 = data[off+1],
+// byte2 = data[off+step], byte3 = data[off+step+1], off = r*step + c, linear addressing
+// (so column cols-1 pairs with the next row's first byte when the image is continuous),
+// bytes past the buffer = 0.  One aligned dword load per bilinear sample.
+struct DevLevel {
+    const uint32_t *quad;
+    int cols, rows;
+    float fcols, frows;     // (float)cols, (float)rows        -- the `x >= img.cols` compare
+    float fcols_m1, frows_m1; // (float)(cols-1), (float)(rows-1) -- the clamp target
+};
+
+struct TrackArgs {
+    DevLevel l1[kMaxLevels], l2[kMaxLevels];
+    float scales[kMaxLevels];
+    int n_levels;
+    int n;
+    const float *pt_ref;
+    const float *pt_init;
+    const float *affine;
+    const uint8_t *status_in;
+    float *pt_un;
+    float *pt_dist;
+    uint8_t *status;
+    double *pix_err;
+    double *dist_pred;
+    float *ncc;
+    int *iters;
+    int half, iterations;
+    int has_gyro, illum, use_affine, penalty, calc_ncc;
+    float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)
+    float lam_invlog_alpha; // mLambda * mInvLogMaxDist * mAlpha   (f32 product, :307)
+    float alpha;
+    double win_size_inv;    // mWinSizeInv (:57)
+    int distort_on;         // mDistCoef(0) != 0 (:410)
+    float fx, fy, cx, cy, fx_inv, fy_inv, k1, k2, p1, p2, k3;
+};
+
+// ---- bilinear sampler ---------------------------------------------------------------------------
+// One coordinate of PatchMatch::GetPixelValue (src/patch_match.cpp:394-401): clamp, integer
+// part, fraction and its complement.
+struct Coord {
+    int i;      // int(x)
+    float f;    // xx = x - floor(x)
+    float omf;  // 1.0f - xx
+};
+
+template <bool CLAMP>
+__device__ __forceinline__ Coord prep_coord(float x, float fmax, float fmax_m1)
+{
+    if (CLAMP) {
+        // `if (x < 0) x = 0;` -- fmaxf also maps NaN to 0 (defined behaviour of this
+        // implementation; the reference's int(NaN) is undefined).  -0.0 vs +0.0 is
+        // immaterial: both give i = 0, xx = 0.
+        x = fmaxf(x, 0.0f);
+        x = (x >= fmax) ? fmax_m1 : x;  // `if (x >= img.cols) x = img.cols - 1;`
+    }
+    Coord c;
+    float fl = floorf(x);
+    c.i = (int)x;
+    c.f = x - fl;
+    c.omf = 1.0f - c.f;
+    return c;
+}
+
+// b*(a*d0 + xx*d1) + yy*(a*d2 + xx*d3), src/patch_match.cpp:402-403, this association.
+__device__ __forceinline__ float bilerp(uint32_t q, const Coord &cx, const Coord &cy)
+{
+    float d0 = (float)(q & 0xffu);
+    float d1 = (float)((q >> 8) & 0xffu);
+    float d2 = (float)((q >> 16) & 0xffu);
+    float d3 = (float)(q >> 24);
+    float top = cx.omf * d0 + cx.f * d1;
+    float bot = cx.omf * d2 + cx.f * d3;
+    return cy.omf * top + cy.f * bot;
+}
+
+template <bool CLAMP>
+__device__ __forceinline__ float sample(const DevLevel &L, float x, float y)
+{
+    Coord cx = prep_coord<CLAMP>(x, L.fcols, L.fcols_m1);
+    Coord cy = prep_coord<CLAMP>(y, L.frows, L.frows_m1);
+    return bilerp(L.quad[cy.i * L.cols + cx.i], cx, cy);
+}
+
+// The five img2 samples one pixel of the GN loop needs (src/patch_match.cpp:252,259-262):
+// centre, x+1, x-1, y+1, y-1.  Each coordinate is prepared once (X+-1 share Y and vice versa).
+struct Five {
+    float c, xp, xm, yp, ym;
+};
+
+template <bool CLAMP>
+__device__ __forceinline__ Five sample5(const DevLevel &L, float X, float Y)
+{
+    Coord cx = prep_coord<CLAMP>(X, L.fcols, L.fcols_m1);
+    Coord cxp = prep_coord<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
+    Coord cxm = prep_coord<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
+    Coord cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
+    Coord cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
+    Coord cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
+    const uint32_t *q = L.quad;
+    int rc = cy.i * L.cols, rp = cyp.i * L.cols, rm = cym.i * L.cols;
+    uint32_t q0 = q[rc + cx.i];
+    uint32_t q1 = q[rc + cxp.i];
+    uint32_t q2 = q[rc + cxm.i];
+    uint32_t q3 = q[rp + cx.i];
+    uint32_t q4 = q[rm + cx.i];
+    Five r;
+    r.c = bilerp(q0, cx, cy);
+    r.xp = bilerp(q1, cxp, cy);
+    r.xm = bilerp(q2, cxm, cy);
+    r.yp = bilerp(q3, cx, cyp);
+    r.ym = bilerp(q4, cx, cym);
+    return r;
+}
+
+// ---- software log (src/patch_match.cpp:305 calls std::log(double)) ------------------------------
+// glibc's log is neither available on the device nor bit-reproducible across hosts; this
+// is a fixed sequence of IEEE double operations (k*ln2 + log1p(f), 7-term series in
+// s = f/(2+f)), < 1 ulp.  The oracle carries the same sequence.
+__device__ __forceinline__ double soft_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (!(x < __builtin_inf())) return x;
+    if (x <= 0.0) return x == 0.0 ? -__builtin_inf() : __builtin_nan("");
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    int k = (int)(u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        k += 1;
+    }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// ---- H.llt().solve(b), update.norm()  (src/patch_match.cpp:319,343) -----------------------------
+// Operation order of Eigen 3.3's fixed-size 4x4 path (unblocked LLT that stops at a
+// non-positive pivot and leaves the rest of the matrix untouched, fully unrolled
+// triangular solves, SSE2-shaped squaredNorm).  M: lower triangle is read and overwritten.
+__device__ __forceinline__ void llt4_inplace(double (&M)[4][4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double x = M[k][k];
+        if (k > 0) {
+            double s = M[k][0] * M[k][0];
+#pragma unroll
+            for (int j = 1; j < k; j++) s += M[k][j] * M[k][j];
+            x -= s;
+        }
+        if (x <= 0.0) return;
+        M[k][k] = x = sqrt(x);
+#pragma unroll
+        for (int i = k + 1; i < 4; i++) {
+            if (k > 0) {
+                double s = M[i][0] * M[k][0];
+#pragma unroll
+                for (int j = 1; j < k; j++) s += M[i][j] * M[k][j];
+                M[i][k] -= s;
+            }
+            M[i][k] /= x;
+        }
+    }
+}
+
+__device__ __forceinline__ double llt4_solve_norm(double (&M)[4][4], const double (&b)[4], double (&x)[4])
+{
+    llt4_inplace(M);
+    double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3];
+    r0 /= M[0][0];
+    r1 -= M[1][0] * r0;
+    r1 /= M[1][1];
+    r2 -= M[2][0] * r0 + M[2][1] * r1;
+    r2 /= M[2][2];
+    r3 -= M[3][0] * r0 + (M[3][1] * r1 + M[3][2] * r2);
+    r3 /= M[3][3];
+    r3 /= M[3][3];
+    r2 -= M[3][2] * r3;
+    r2 /= M[2][2];
+    r1 -= M[2][1] * r2 + M[3][1] * r3;
+    r1 /= M[1][1];
+    r0 -= (M[1][0] * r1 + M[2][0] * r2) + M[3][0] * r3;
+    r0 /= M[0][0];
+    x[0] = r0;
+    x[1] = r1;
+    x[2] = r2;
+    x[3] = r3;
+    return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
+}
+
+// Gyro regularisation penalty, src/patch_match.cpp:302-314.  Adds to H (lower triangle
+// only: LLT reads nothing else), b and cost.
+__device__ __forceinline__ void add_penalty(const TrackArgs &a, float dx, float dy, double (&H)[4][4],
+                                            double (&b)[4], float &cost)
+{
+    double d = (double)sqrtf(dx * dx + dy * dy);                                       // :304
+    double e_pen = (double)a.lam_invlog * soft_log((double)a.alpha * d + 1);           // :305
+    double jx = (double)a.lam_invlog_alpha / ((double)a.alpha * d + 1) * ((double)dx / d); // :307
+    double jy = (double)a.lam_invlog_alpha / ((double)a.alpha * d + 1) * ((double)dy / d); // :308
+    H[0][0] += jx * jx;                                                                // :311
+    H[1][0] += jy * jx;
+    H[1][1] += jy * jy;
+    // rows/cols 2,3 of JPenalty are 0: H += 0*x adds +0.0 and changes nothing unless jx/jy
+    // are NaN/inf (d == 0 gives 0/0): then 0*NaN = NaN lands in those entries too.
+    H[2][0] += 0.0 * jx;
+    H[2][1] += 0.0 * jy;
+    H[2][2] += 0.0 * 0.0;
+    H[3][0] += 0.0 * jx;
+    H[3][1] += 0.0 * jy;
+    H[3][2] += 0.0 * 0.0;
+    H[3][3] += 0.0 * 0.0;
+    b[0] += jx * e_pen;                                                                // :312 (PLUS)
+    b[1] += jy * e_pen;
+    b[2] += 0.0 * e_pen;
+    b[3] += 0.0 * e_pen;
+    cost = (float)((double)cost + e_pen * e_pen);                                      // :313
+}
+
+// DistortVecPoints, src/utils.cpp:49-76, one point.
+__device__ __forceinline__ void distort_point(const TrackArgs &a, float ux, float uy, float &ox, float &oy)
+{
+    if (!a.distort_on) {  // src/patch_match.cpp:410-411
+        ox = ux;
+        oy = uy;
+        return;
+    }
+    float x = (ux - a.cx) * a.fx_inv;
+    float y = (uy - a.cy) * a.fy_inv;
+    float r2 = x * x + y * y;
+    float r4 = r2 * r2;
+    float r6 = r4 * r2;
+    float xd = x * (1 + a.k1 * r2 + a.k2 * r4 + a.k3 * r6) + 2 * a.p1 * x * y + a.p2 * (r2 + 2 * x * x);
+    float yd = y * (1 + a.k1 * r2 + a.k2 * r4 + a.k3 * r6) + a.p1 * (r2 + 2 * y * y) + 2 * a.p2 * x * y;
+    ox = a.fx * xd + a.cx;
+    oy = a.fy * yd + a.cy;
+}
+
+}  // namespace pagk

@@ -1,0 +1,646 @@
+// pagk_hip.hip -- C ABI (include/pagk.h) over the gfx950 kernels.  Host side of the boundary.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared  (see __graft_entry__.py)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/pagk.h"
+#include "pagk_kernels.h"
+
+using namespace pagk;
+
+namespace {
+
+constexpr int kSlots = 4;
+
+struct FrameSlot {
+    int w = 0, h = 0, L = 0;
+    int wrap0 = 1;                   // level-0 source was continuous (step == cols)
+    uint8_t *u8[kMaxLevels] = {};    // u8[0] is our contiguous copy of level 0 (pitch = w)
+    uint32_t *quad[kMaxLevels] = {};
+    void *block = nullptr;           // one allocation for everything above
+    size_t block_bytes = 0;
+    bool valid = false;
+};
+
+struct FeatBuf {
+    void *block = nullptr;
+    size_t bytes = 0;
+    int cap = 0;
+};
+
+}  // namespace
+
+struct pagk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    FrameSlot slots[kSlots];
+    FeatBuf feat;
+    hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
+    bool trk_timed = false, pyr_timed = false;
+    int kernel = 0;
+    char err[256] = {0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,     \
+                     hipGetErrorString(e_));                                                           \
+            return e_ == hipErrorOutOfMemory ? PAGK_E_NOMEM : PAGK_E_HIP;                              \
+        }                                                                                              \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int level_dims(int w, int h, int L, int *lw, int *lh)
+{
+    lw[0] = w;
+    lh[0] = h;
+    for (int l = 1; l < L; l++) {
+        // src/patch_match.cpp:69  cv::Size(cols * 0.5, rows * 0.5); only the exact-2x path of
+        // cv::resize is implemented: parents must be even.
+        if ((lw[l - 1] & 1) || (lh[l - 1] & 1)) return PAGK_E_UNSUPPORTED;
+        lw[l] = (int)(lw[l - 1] * 0.5);
+        lh[l] = (int)(lh[l - 1] * 0.5);
+        if (lw[l] < 1 || lh[l] < 1) return PAGK_E_ARG;
+    }
+    return PAGK_OK;
+}
+
+int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
+{
+    int lw[kMaxLevels], lh[kMaxLevels];
+    int rc = level_dims(w, h, L, lw, lh);
+    if (rc) return rc;
+    size_t total = 0, off_u8[kMaxLevels], off_q[kMaxLevels];
+    for (int l = 0; l < L; l++) {
+        off_u8[l] = total;
+        total = align_up(total + (size_t)lw[l] * lh[l], 256);
+    }
+    for (int l = 0; l < L; l++) {
+        off_q[l] = total;
+        total = align_up(total + (size_t)lw[l] * lh[l] * 4, 256);
+    }
+    if (total > s.block_bytes) {
+        if (s.block) HIPCHK(ctx, hipFree(s.block));
+        s.block = nullptr;
+        s.block_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&s.block, total));
+        s.block_bytes = total;
+    }
+    for (int l = 0; l < L; l++) {
+        s.u8[l] = static_cast<uint8_t *>(s.block) + off_u8[l];
+        s.quad[l] = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(s.block) + off_q[l]);
+    }
+    s.w = w;
+    s.h = h;
+    s.L = L;
+    return PAGK_OK;
+}
+
+// CreatePyramids (src/patch_match.cpp:61-76) + tap packing, from a level-0 image that is
+// already on the device at (src0, pitch0).
+int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0, int wrap0)
+{
+    int lw[kMaxLevels], lh[kMaxLevels];
+    level_dims(s.w, s.h, s.L, lw, lh);
+    dim3 blk(32, 8);
+    if (ctx->ev_pyr[0]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
+    const uint8_t *src = src0;
+    int64_t pitch = pitch0;
+    for (int l = 0; l < s.L; l++) {
+        if (l > 0) {
+            dim3 grd((lw[l] + 31) / 32, (lh[l] + 7) / 8);
+            hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, ctx->stream, src, pitch, lw[l], lh[l], s.u8[l]);
+            src = s.u8[l];
+            pitch = lw[l];
+        }
+        dim3 grd((lw[l] + 31) / 32, (lh[l] + 7) / 8);
+        hipLaunchKernelGGL(k_build_quads, grd, blk, 0, ctx->stream, src, pitch, lw[l], lh[l], l == 0 ? wrap0 : 1,
+                           s.quad[l]);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->ev_pyr[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+    ctx->pyr_timed = true;
+    s.wrap0 = wrap0;
+    s.valid = true;
+    return PAGK_OK;
+}
+
+int check_params(const pagk_params *p)
+{
+    if (!p) return PAGK_E_ARG;
+    if (p->half_patch < 1 || p->half_patch > PAGK_MAX_HALF_PATCH) return PAGK_E_ARG;
+    if (p->iterations < 0 || p->pyramids < 1 || p->pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
+    if (p->inverse) return PAGK_E_UNSUPPORTED;        // src/patch_match.cpp:220 "not support yet"
+    if (p->calculate_ncc) return PAGK_E_UNSUPPORTED;  // PatchMatch::NCC (:433-469): next row, see DESIGN.md
+    return PAGK_OK;
+}
+
+void fill_level(DevLevel &d, const FrameSlot &s, int l)
+{
+    int w = s.w, h = s.h;
+    for (int k = 0; k < l; k++) {
+        w = (int)(w * 0.5);
+        h = (int)(h * 0.5);
+    }
+    d.quad = s.quad[l];
+    d.cols = w;
+    d.rows = h;
+    d.fcols = (float)w;
+    d.frows = (float)h;
+    d.fcols_m1 = (float)(w - 1);
+    d.frows_m1 = (float)(h - 1);
+}
+
+int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
+                 const float *d_pt_ref, const float *d_pt_init, const float *d_affine, const uint8_t *d_status,
+                 const pagk_outputs *o)
+{
+    TrackArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_levels = p->pyramids;
+    for (int l = 0; l < p->pyramids; l++) {
+        fill_level(a.l1[l], sr, l);
+        fill_level(a.l2[l], sc, l);
+        // :66,:73  mvScales[i] = mvScales[i-1] * mPyramidScale  (float * double -> float)
+        a.scales[l] = l == 0 ? 1.0f : (float)((double)a.scales[l - 1] * 0.5);
+    }
+    a.n = n;
+    a.pt_ref = d_pt_ref;
+    a.pt_init = d_pt_init;
+    a.affine = d_affine;
+    a.status_in = d_status;
+    a.pt_un = o->pt_un;
+    a.pt_dist = o->pt_dist;
+    a.status = o->status;
+    a.pix_err = o->pix_err;
+    a.dist_pred = o->dist_pred;
+    a.ncc = o->ncc;
+    a.iters = o->iters;
+    a.half = p->half_patch;
+    a.iterations = p->iterations;
+    a.has_gyro = p->has_gyro_predict_initial;
+    a.illum = p->consider_illumination;
+    a.use_affine = p->consider_affine;
+    a.penalty = p->regularization_penalty;
+    a.calc_ncc = p->calculate_ncc;
+    float invlog = p->inv_log_max_dist != 0.0f ? p->inv_log_max_dist
+                                               : pagk_inv_log_max_dist(p->alpha, p->max_distance);
+    a.lam_invlog = p->lambda * invlog;           // :305  mLambda * mInvLogMaxDist (float)
+    a.lam_invlog_alpha = a.lam_invlog * p->alpha; // :307  ... * mAlpha (float)
+    a.alpha = p->alpha;
+    // :57  1.0f / (2.0f*h + 1.0f) / (2.0f*h + 1.0f), float, stored in a double
+    a.win_size_inv = (double)(1.0f / (2.0f * p->half_patch + 1.0f) / (2.0f * p->half_patch + 1.0f));
+    a.distort_on = p->dist_coef[0] != 0.0f;  // :410
+    a.fx = p->fx, a.fy = p->fy, a.cx = p->cx, a.cy = p->cy;
+    a.fx_inv = (float)(1.0 / (double)p->fx);  // src/utils.cpp:53
+    a.fy_inv = (float)(1.0 / (double)p->fy);
+    a.k1 = p->dist_coef[0], a.k2 = p->dist_coef[1], a.p1 = p->dist_coef[2], a.p2 = p->dist_coef[3];
+    a.k3 = p->n_dist_coef == 5 ? p->dist_coef[4] : 0.0f;
+
+    if (ctx->ev_trk[0]) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
+    if (n > 0) {
+        if (ctx->kernel == 1) {
+            hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        } else {
+            const int P = (2 * a.half + 1) * (2 * a.half + 1);
+            const int nr = (P + kBlock - 1) / kBlock;
+            const size_t lds = track_block_lds_bytes(a.half);
+            auto launch = [&](auto kern) -> hipError_t {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(n), dim3(kBlock), lds, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e;
+            switch (nr) {
+                case 1: e = launch(k_track_block<1>); break;
+                case 2: e = launch(k_track_block<2>); break;
+                case 3: e = launch(k_track_block<3>); break;
+                default: e = launch(k_track_block<4>); break;
+            }
+            HIPCHK(ctx, e);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (ctx->ev_trk[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[1], ctx->stream));
+    ctx->trk_timed = true;
+    return PAGK_OK;
+}
+
+// device staging for the host-buffer path: one block holding every per-feature array
+struct FeatPtrs {
+    float *pt_ref, *pt_init, *affine;
+    uint8_t *status_in;
+    pagk_outputs out;
+};
+
+int feat_reserve(pagk_ctx *ctx, int n, FeatPtrs *fp)
+{
+    int cap = n < 1 ? 1 : n;
+    // per feature: 8+8+16+1 in, 8+8+1+8+8+4+4 out; every array 256-aligned
+    size_t sizes[11] = {8, 8, 16, 1, 8, 8, 1, 8, 8, 4, 4};
+    size_t offs[11], total = 0;
+    for (int k = 0; k < 11; k++) {
+        offs[k] = total;
+        total = align_up(total + sizes[k] * (size_t)cap, 256);
+    }
+    if (total > ctx->feat.bytes) {
+        if (ctx->feat.block) HIPCHK(ctx, hipFree(ctx->feat.block));
+        ctx->feat.block = nullptr;
+        ctx->feat.bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->feat.block, total));
+        ctx->feat.bytes = total;
+    }
+    uint8_t *b = static_cast<uint8_t *>(ctx->feat.block);
+    fp->pt_ref = reinterpret_cast<float *>(b + offs[0]);
+    fp->pt_init = reinterpret_cast<float *>(b + offs[1]);
+    fp->affine = reinterpret_cast<float *>(b + offs[2]);
+    fp->status_in = b + offs[3];
+    fp->out.pt_un = reinterpret_cast<float *>(b + offs[4]);
+    fp->out.pt_dist = reinterpret_cast<float *>(b + offs[5]);
+    fp->out.status = b + offs[6];
+    fp->out.pix_err = reinterpret_cast<double *>(b + offs[7]);
+    fp->out.dist_pred = reinterpret_cast<double *>(b + offs[8]);
+    fp->out.ncc = reinterpret_cast<float *>(b + offs[9]);
+    fp->out.iters = reinterpret_cast<int32_t *>(b + offs[10]);
+    return PAGK_OK;
+}
+
+int upload_level0(pagk_ctx *ctx, FrameSlot &s, const pagk_image *img)
+{
+    HIPCHK(ctx, hipMemcpy2DAsync(s.u8[0], (size_t)s.w, img->data, (size_t)img->step, (size_t)s.w, (size_t)s.h,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    return PAGK_OK;
+}
+
+int check_image(const pagk_image *im)
+{
+    if (!im || !im->data || im->width < 1 || im->height < 1 || im->step < im->width) return PAGK_E_ARG;
+    return PAGK_OK;
+}
+
+int track_host_common(pagk_ctx *ctx, const pagk_params *p, int n, const float *pt_ref, const float *pt_init,
+                      const float *affine, const uint8_t *status_in, const pagk_outputs *out, FrameSlot &sr,
+                      FrameSlot &sc)
+{
+    if (n < 0 || !out || !out->pt_un || !out->status) return PAGK_E_ARG;
+    if (n > 0 && (!pt_ref || !status_in)) return PAGK_E_ARG;
+    if (n > 0 && p->has_gyro_predict_initial && !pt_init) return PAGK_E_ARG;
+    if (n > 0 && p->consider_affine && !affine) return PAGK_E_ARG;
+    FeatPtrs fp;
+    int rc = feat_reserve(ctx, n, &fp);
+    if (rc) return rc;
+    if (n > 0) {
+        size_t nn = (size_t)n;
+        HIPCHK(ctx, hipMemcpyAsync(fp.pt_ref, pt_ref, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (pt_init) HIPCHK(ctx, hipMemcpyAsync(fp.pt_init, pt_init, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (affine) HIPCHK(ctx, hipMemcpyAsync(fp.affine, affine, nn * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(fp.status_in, status_in, nn, hipMemcpyHostToDevice, ctx->stream));
+    }
+    pagk_outputs dout = fp.out;
+    if (!out->pt_dist) dout.pt_dist = nullptr;
+    if (!out->pix_err) dout.pix_err = nullptr;
+    if (!out->dist_pred) dout.dist_pred = nullptr;
+    if (!out->ncc) dout.ncc = nullptr;
+    if (!out->iters) dout.iters = nullptr;
+    rc = launch_track(ctx, p, sr, sc, n, fp.pt_ref, pt_init ? fp.pt_init : nullptr, affine ? fp.affine : nullptr,
+                      fp.status_in, &dout);
+    if (rc) return rc;
+    if (n > 0) {
+        size_t nn = (size_t)n;
+        HIPCHK(ctx, hipMemcpyAsync(out->pt_un, dout.pt_un, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out->status, dout.status, nn, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->pt_dist) HIPCHK(ctx, hipMemcpyAsync(out->pt_dist, dout.pt_dist, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->pix_err) HIPCHK(ctx, hipMemcpyAsync(out->pix_err, dout.pix_err, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->dist_pred) HIPCHK(ctx, hipMemcpyAsync(out->dist_pred, dout.dist_pred, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->ncc) HIPCHK(ctx, hipMemcpyAsync(out->ncc, dout.ncc, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->iters) HIPCHK(ctx, hipMemcpyAsync(out->iters, dout.iters, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int pagk_version(void) { return PAGK_VERSION; }
+
+const char *pagk_strerror(int code)
+{
+    switch (code) {
+        case PAGK_OK: return "ok";
+        case PAGK_E_ARG: return "invalid argument";
+        case PAGK_E_HIP: return "HIP runtime error";
+        case PAGK_E_NOMEM: return "out of memory";
+        case PAGK_E_UNSUPPORTED: return "unsupported mode";
+        case PAGK_E_NODEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+const char *pagk_last_error(const pagk_ctx *ctx) { return ctx ? ctx->err : ""; }
+
+// Reference call site src/gyro_aided_tracker.cpp:276-282 and eType 4 (:402-408).
+void pagk_params_default(pagk_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->half_patch = 5;
+    p->iterations = 10;
+    p->pyramids = 3;
+    p->has_gyro_predict_initial = 1;
+    p->inverse = 0;
+    p->consider_illumination = 1;
+    p->consider_affine = 1;
+    p->regularization_penalty = 0;
+    p->calculate_ncc = 0;
+    p->lambda = 1.0f;      // src/patch_match.cpp:48
+    p->alpha = 0.5f;       // :49
+    p->max_distance = 25;  // :50
+    p->inv_log_max_dist = 0.0f;
+    p->fx = p->fy = 1.0f;
+    p->n_dist_coef = 4;
+}
+
+// src/patch_match.cpp:51  mInvLogMaxDist = 1.0 / (std::log(mAlpha * mMaxDistance + 1));
+// float * int -> float, + 1 -> float, std::log(float) -> float, 1.0 / float -> double -> float member.
+float pagk_inv_log_max_dist(float alpha, int32_t max_distance)
+{
+    float arg = alpha * (float)max_distance + 1;
+    float lg = std::log(arg);
+    return (float)(1.0 / (double)lg);
+}
+
+int pagk_create(pagk_ctx **out, int device)
+{
+    if (!out) return PAGK_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PAGK_E_NODEVICE;
+    if (device < 0 || device >= ndev) return PAGK_E_ARG;
+    pagk_ctx *ctx = new (std::nothrow) pagk_ctx();
+    if (!ctx) return PAGK_E_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PAGK_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (int k = 0; k < 2; k++) {
+        if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
+            pagk_destroy(ctx);
+            return PAGK_E_HIP;
+        }
+    }
+    *out = ctx;
+    return PAGK_OK;
+}
+
+void pagk_destroy(pagk_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (auto &s : ctx->slots)
+        if (s.block) (void)hipFree(s.block);
+    if (ctx->feat.block) (void)hipFree(ctx->feat.block);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
+        if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PAGK_E_ARG;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return PAGK_OK;
+}
+
+int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
+{
+    if (!ctx || which < 0 || which > 1) return PAGK_E_ARG;
+    ctx->kernel = which;
+    return PAGK_OK;
+}
+
+int pagk_sync(pagk_ctx *ctx)
+{
+    if (!ctx) return PAGK_E_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
+}
+
+int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms)
+{
+    if (!ctx) return PAGK_E_ARG;
+    if (track_ms) {
+        *track_ms = 0.0f;
+        if (ctx->trk_timed) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev_trk[1]));
+            HIPCHK(ctx, hipEventElapsedTime(track_ms, ctx->ev_trk[0], ctx->ev_trk[1]));
+        }
+    }
+    if (pyramid_ms) {
+        *pyramid_ms = 0.0f;
+        if (ctx->pyr_timed) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev_pyr[1]));
+            HIPCHK(ctx, hipEventElapsedTime(pyramid_ms, ctx->ev_pyr[0], ctx->ev_pyr[1]));
+        }
+    }
+    return PAGK_OK;
+}
+
+int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
+{
+    if (!ctx || slot < 0 || slot >= kSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
+    int rc = check_image(img);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FrameSlot &s = ctx->slots[slot];
+    s.valid = false;
+    if ((rc = slot_reserve(ctx, s, img->width, img->height, pyramids))) return rc;
+    if ((rc = upload_level0(ctx, s, img))) return rc;
+    return slot_build(ctx, s, s.u8[0], s.w, img->step == img->width);
+}
+
+int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width, int32_t height,
+                          int64_t step, int32_t pyramids)
+{
+    if (!ctx || slot < 0 || slot >= kSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
+    if (!d_data || width < 1 || height < 1 || step < width) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FrameSlot &s = ctx->slots[slot];
+    s.valid = false;
+    int rc = slot_reserve(ctx, s, width, height, pyramids);
+    if (rc) return rc;
+    // level 0 is read in place: no copy
+    return slot_build(ctx, s, static_cast<const uint8_t *>(d_data), step, step == width);
+}
+
+int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst, int32_t *width,
+                              int32_t *height)
+{
+    if (!ctx || slot < 0 || slot >= kSlots || !dst) return PAGK_E_ARG;
+    FrameSlot &s = ctx->slots[slot];
+    if (!s.valid || level < 1 || level >= s.L) return PAGK_E_ARG;  // level 0 is the caller's own image
+    int lw[kMaxLevels], lh[kMaxLevels];
+    level_dims(s.w, s.h, s.L, lw, lh);
+    HIPCHK(ctx, hipMemcpyAsync(dst, s.u8[level], (size_t)lw[level] * lh[level], hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (width) *width = lw[level];
+    if (height) *height = lh[level];
+    return PAGK_OK;
+}
+
+int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref, int32_t slot_cur, int32_t n,
+                      const float *d_pt_ref_un, const float *d_pt_init_un, const float *d_affine,
+                      const uint8_t *d_status_in, const pagk_outputs *d_out)
+{
+    if (!ctx) return PAGK_E_ARG;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (slot_ref < 0 || slot_ref >= kSlots || slot_cur < 0 || slot_cur >= kSlots) return PAGK_E_ARG;
+    FrameSlot &sr = ctx->slots[slot_ref], &sc = ctx->slots[slot_cur];
+    if (!sr.valid || !sc.valid || sr.L < params->pyramids || sc.L < params->pyramids) return PAGK_E_ARG;
+    if (sr.w != sc.w || sr.h != sc.h) return PAGK_E_ARG;
+    if (n < 0 || !d_out || !d_out->pt_un || !d_out->status) return PAGK_E_ARG;
+    if (n > 0 && (!d_pt_ref_un || !d_status_in)) return PAGK_E_ARG;
+    if (n > 0 && params->has_gyro_predict_initial && !d_pt_init_un) return PAGK_E_ARG;
+    if (n > 0 && params->consider_affine && !d_affine) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out);
+}
+
+int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref, const pagk_image *cur, int32_t n,
+               const float *pt_ref_un, const float *pt_init_un, const float *affine, const uint8_t *status_in,
+               const pagk_outputs *out)
+{
+    if (!ctx) return PAGK_E_ARG;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if ((rc = check_image(ref)) || (rc = check_image(cur))) return rc;
+    if (ref->width != cur->width || ref->height != cur->height) return PAGK_E_ARG;
+    // slots 2/3 are the scratch pair of the host-buffer path
+    if ((rc = pagk_frame_upload(ctx, 2, ref, params->pyramids))) return rc;
+    if ((rc = pagk_frame_upload(ctx, 3, cur, params->pyramids))) return rc;
+    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[2],
+                             ctx->slots[3]);
+}
+
+int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, const pagk_image *ref_levels,
+                   const pagk_image *cur_levels, int32_t n, const float *pt_ref_un, const float *pt_init_un,
+                   const float *affine, const uint8_t *status_in, const pagk_outputs *out)
+{
+    if (!ctx || !ref_levels || !cur_levels) return PAGK_E_ARG;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n_levels != params->pyramids) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // caller-built pyramids: every level is uploaded and packed as is; level sizes must be
+    // the ones CreatePyramids would produce (int(cols*0.5)), but parents may be odd.
+    FrameSlot *sl[2] = {&ctx->slots[2], &ctx->slots[3]};
+    const pagk_image *lv[2] = {ref_levels, cur_levels};
+    for (int k = 0; k < 2; k++) {
+        for (int l = 0; l < n_levels; l++)
+            if ((rc = check_image(&lv[k][l]))) return rc;
+        int w = lv[k][0].width, h = lv[k][0].height;
+        for (int l = 1; l < n_levels; l++) {
+            w = (int)(w * 0.5);
+            h = (int)(h * 0.5);
+            if (lv[k][l].width != w || lv[k][l].height != h) return PAGK_E_ARG;
+        }
+        if (lv[k][0].width != lv[0][0].width || lv[k][0].height != lv[0][0].height) return PAGK_E_ARG;
+        FrameSlot &s = *sl[k];
+        s.valid = false;
+        // reserve without the even-parent restriction
+        size_t total = 0, off_u8[kMaxLevels], off_q[kMaxLevels];
+        for (int l = 0; l < n_levels; l++) {
+            off_u8[l] = total;
+            total = align_up(total + (size_t)lv[k][l].width * lv[k][l].height, 256);
+        }
+        for (int l = 0; l < n_levels; l++) {
+            off_q[l] = total;
+            total = align_up(total + (size_t)lv[k][l].width * lv[k][l].height * 4, 256);
+        }
+        if (total > s.block_bytes) {
+            if (s.block) HIPCHK(ctx, hipFree(s.block));
+            s.block = nullptr;
+            s.block_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&s.block, total));
+            s.block_bytes = total;
+        }
+        s.w = lv[k][0].width;
+        s.h = lv[k][0].height;
+        s.L = n_levels;
+        dim3 blk(32, 8);
+        for (int l = 0; l < n_levels; l++) {
+            const pagk_image &im = lv[k][l];
+            s.u8[l] = static_cast<uint8_t *>(s.block) + off_u8[l];
+            s.quad[l] = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(s.block) + off_q[l]);
+            HIPCHK(ctx, hipMemcpy2DAsync(s.u8[l], (size_t)im.width, im.data, (size_t)im.step, (size_t)im.width,
+                                         (size_t)im.height, hipMemcpyHostToDevice, ctx->stream));
+            dim3 grd((im.width + 31) / 32, (im.height + 7) / 8);
+            hipLaunchKernelGGL(k_build_quads, grd, blk, 0, ctx->stream, (const uint8_t *)s.u8[l], (int64_t)im.width,
+                               im.width, im.height, im.step == im.width ? 1 : 0, s.quad[l]);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        s.valid = true;
+    }
+    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[2],
+                             ctx->slots[3]);
+}
+
+// GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined, Step 3,
+// src/gyro_aided_tracker.cpp:289-341.  O(n) host arithmetic on the gathered results.
+int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm, const double *pix_err,
+                     const double *dist_pred, const float *pt_pm, const float *pt_pm_un, uint8_t *status_out,
+                     float *pt_predict, float *pt_predict_un)
+{
+    if (n < 0 || (n > 0 && (!status_pm || !pix_err || !dist_pred || !status_out))) return PAGK_E_ARG;
+    double sum = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i)
+        if (status_pm[i]) {  // :298
+            sum += pix_err[i];
+            cnt++;
+        }
+    const double avg = sum / cnt;  // :305 (cnt == 0 -> NaN -> threshold falls back to h)
+    const double th_pix = 4.0 * avg > half_patch ? 4.0 * avg : half_patch;  // :308
+    const double th_dist = half_patch * 4.0;                                // :312
+    int kept = 0;
+    for (int i = 0; i < n; i++) {  // :318
+        const bool ok = status_pm[i] && pix_err[i] < th_pix && dist_pred[i] < th_dist;
+        status_out[i] = ok ? 1 : 0;
+        if (!ok) continue;
+        if (pt_predict && pt_pm) {
+            pt_predict[2 * i] = pt_pm[2 * i];
+            pt_predict[2 * i + 1] = pt_pm[2 * i + 1];
+        }
+        if (pt_predict_un && pt_pm_un) {
+            pt_predict_un[2 * i] = pt_pm_un[2 * i];
+            pt_predict_un[2 * i + 1] = pt_pm_un[2 * i + 1];
+        }
+        kept++;
+    }
+    return kept;
+}
+
+}  // extern "C"

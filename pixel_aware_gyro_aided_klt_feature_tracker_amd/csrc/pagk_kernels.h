@@ -1,0 +1,372 @@
+// pagk_kernels.h -- gfx950 kernels of the PatchMatch hot path.
+//
+//   k_pyr_down      CreatePyramids               src/patch_match.cpp:61-76
+//   k_build_quads   tap packing for the sampler  src/patch_match.cpp:399-403
+//   k_track_block   the GN loop, one 256-thread workgroup per feature (default)
+//   k_track_thread  the GN loop, one thread per feature (reference-shaped cross-check)
+//
+// Why one workgroup per feature.  H is structurally singular (de_dg is sampled at the patch
+// centre, :263, so J3 = c*J4): the 4th LLT pivot is rounding noise, that noise is applied to
+// dg/db (:334-337) and enters the convergence test (:343).  Results within 1e-3 px of the CPU
+// path therefore need H, b and cost accumulated in the reference's order: (2h+1)^2 sequential
+// f64 (f32 for cost) additions per entry per iteration.  That chain is the critical path of a
+// feature.  The kernel keeps it as short as the hardware allows: all 256 lanes sample the patch
+// and form the EXACT f64 products (24-bit x 24-bit fits 53 bits, so the product and
+// multiply-add orders agree), stage them in LDS, and then one lane per accumulator entry walks
+// its array with one ds_read_b64 + one v_add_f64 per pixel.
+#pragma once
+#include "pagk_device.h"
+
+namespace pagk {
+
+// ---- pyramid -----------------------------------------------------------------------------------
+// cv::resize(prev, Size(cols*0.5, rows*0.5)), src/patch_match.cpp:69-70: exact 2x
+// decimation of 8UC1 = OpenCV's INTER_AREA fast path, (a+b+c+d+2)>>2.
+__global__ void k_pyr_down(const uint8_t *__restrict__ src, int64_t pitch, int dw, int dh,
+                           uint8_t *__restrict__ dst)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint8_t *r0 = src + (int64_t)(2 * y) * pitch + 2 * x;
+    const uint8_t *r1 = r0 + pitch;
+    dst[(int64_t)y * dw + x] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+}
+
+// Packs the taps of GetPixelValue for every pixel (see DevLevel).  `wrap` = the source
+// image is continuous (step == cols): data[off+1] of the last column is the next row's
+// first pixel.  Otherwise that byte is row padding, defined as 0.  Rows past the image = 0.
+__global__ void k_build_quads(const uint8_t *__restrict__ src, int64_t pitch, int cols, int rows, int wrap,
+                              uint32_t *__restrict__ quad)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (c >= cols || r >= rows) return;
+    auto px = [&](int rr, int cc) -> uint32_t {
+        if (cc >= cols) {
+            if (!wrap) return 0u;
+            cc -= cols;
+            rr += 1;
+        }
+        return rr < rows ? (uint32_t)src[(int64_t)rr * pitch + cc] : 0u;
+    };
+    uint32_t d0 = px(r, c), d1 = px(r, c + 1), d2 = px(r + 1, c), d3 = px(r + 1, c + 1);
+    quad[(int64_t)r * cols + c] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+}
+
+// ---- shared epilogue: SetMatcher + DistortPoints for one feature --------------------------------
+__device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
+                                              float lastCost, int level0_ran, float ncc, int iters)
+{
+    a.pt_un[2 * i] = p2x;      // mvPtPredictAfterPatchMatchedUn  (:380)
+    a.pt_un[2 * i + 1] = p2y;
+    a.status[i] = (uint8_t)(level0_ran ? succ : 0);  // :351, :381 (zero-init when skipped)
+    if (a.pix_err) a.pix_err[i] = level0_ran ? sqrt((double)lastCost * a.win_size_inv) : 0.0;  // :352
+    if (a.dist_pred) {  // :384-385
+        const float *pred = a.pt_init ? a.pt_init : a.pt_ref;
+        float ddx = pred[2 * i] - p2x, ddy = pred[2 * i + 1] - p2y;
+        a.dist_pred[i] = (double)sqrtf(ddx * ddx + ddy * ddy);
+    }
+    if (a.pt_dist) {  // :116, :379
+        float ox, oy;
+        distort_point(a, p2x, p2y, ox, oy);
+        a.pt_dist[2 * i] = ox;
+        a.pt_dist[2 * i + 1] = oy;
+    }
+    if (a.ncc) a.ncc[i] = ncc;  // :365 / :95
+    if (a.iters) a.iters[i] = iters;
+}
+
+// ---- one thread per feature: the reference's loop nest, verbatim in shape -----------------------
+// PatchMatch::OpticalFlowConsideringIlluminationChange_onePixel, src/patch_match.cpp:167-367,
+// with the level loop of OpticalFlowMultiLevel (:98) folded in (features are independent
+// across levels).  Slow (scattered gathers, divergent trip counts); kept as an on-device
+// cross-check of k_track_block.
+__global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
+    float p2x = init[2 * i], p2y = init[2 * i + 1];
+    if (!a.status_in[i]) {  // :173
+        write_outputs(a, i, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
+        return;
+    }
+    const int h = a.half;
+    float A00 = 1, A01 = 0, A10 = 0, A11 = 1;
+    if (a.use_affine) {
+        A00 = a.affine[4 * i], A01 = a.affine[4 * i + 1], A10 = a.affine[4 * i + 2], A11 = a.affine[4 * i + 3];
+    }
+    int succ = 1, iters = 0;
+    float lastCost = 0.0f;
+    for (int level = a.n_levels - 1; level >= 0; level--) {
+        const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
+        float ptx = a.pt_ref[2 * i] * a.scales[level], pty = a.pt_ref[2 * i + 1] * a.scales[level];  // :177
+        float nx, ny;
+        if (level == a.n_levels - 1) {  // :180
+            nx = p2x * a.scales[level];
+            ny = p2y * a.scales[level];
+        } else {  // :182
+            nx = (float)((double)(p2x * 1.0f) / 0.5);
+            ny = (float)((double)(p2y * 1.0f) / 0.5);
+        }
+        float dx = nx - ptx, dy = ny - pty, dg = 0.0f, db = 0.0f, cost = 0.0f;
+        lastCost = 0.0f;
+        succ = 1;
+        float cneg = -sample<true>(L1, ptx, pty);  // :263
+        for (int iter = 0; iter < a.iterations; iter++) {
+            double H[4][4] = {}, b[4] = {};
+            iters++;
+            cost = 0;
+            for (int y = -h; y <= h; y++)
+                for (int x = -h; x <= h; x++) {
+                    float wx = (float)x, wy = (float)y;
+                    if (a.use_affine) {  // :203-204
+                        wx = A00 * x + A01 * y;
+                        wy = A10 * x + A11 * y;
+                    }
+                    Five s = sample5<true>(L2, ptx + dx + wx, pty + dy + wy);
+                    float e = s.c + db - (1.0f + dg) * sample<true>(L1, ptx + x, pty + y);  // :252-253
+                    float Ix = 0.5f * (s.xp - s.xm);                                           // :259
+                    float Iy = 0.5f * (s.yp - s.ym);                                           // :261
+                    double J[4] = {(double)Ix, (double)Iy, (double)cneg, 1.0};
+                    double ed = (double)e;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b[r] += (-J[r]) * ed;  // :293
+                    cost += e * e;                                     // :294
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) H[r][c] += J[r] * J[c];  // :296 (lower triangle)
+                }
+            if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+            double upd[4];
+            double unorm = llt4_solve_norm(H, b, upd);  // :319
+            if (upd[0] != upd[0]) {                     // :322
+                succ = 0;
+                break;
+            }
+            if (iter > 0 && cost > lastCost) break;  // :328
+            dx = (float)((double)dx + upd[0]);       // :332
+            dy = (float)((double)dy + upd[1]);
+            if (a.illum) {
+                dg = (float)((double)dg + upd[2]);
+                db = (float)((double)db + upd[3]);
+            }
+            lastCost = cost;
+            succ = 1;
+            if (unorm < 1e-2) break;  // :343
+        }
+        p2x = ptx + dx;  // :348
+        p2y = pty + dy;
+    }
+    write_outputs(a, i, p2x, p2y, succ, lastCost, 1, 1.0f, iters);
+}
+
+// ---- one workgroup per feature -----------------------------------------------------------------
+// NR = ceil((2h+1)^2 / 256): pixels per lane.  Dynamic LDS:
+//   double prod[11][PP]   exact f64 products, one array per accumulator entry, PP = P rounded
+//                         up to even.  Entry order: H00 H10 H11 H20 H21 H30 H31 b0 b1 b2 b3
+//   float  esq[PP]        f32-rounded e*e (the `cost` chain, :294)
+//   double acc[12]        chain results (acc[11] = H22)
+//   double upd[5]         update[0..3], norm
+//   float  costs[2], int flags
+constexpr int kBlock = 256;
+constexpr int kChains = 11;
+
+__host__ __device__ inline size_t track_block_lds_bytes(int half)
+{
+    int P = (2 * half + 1) * (2 * half + 1);
+    int PP = (P + 1) & ~1;
+    return (size_t)kChains * PP * 8 + (size_t)PP * 4 + 12 * 8 + 5 * 8 + 16;
+}
+
+template <int NR>
+__global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = (P + 1) & ~1;
+
+    double *prod = reinterpret_cast<double *>(lds_raw);
+    float *esq = reinterpret_cast<float *>(prod + (size_t)kChains * PP);
+    double *acc = reinterpret_cast<double *>(esq + PP);
+    double *sh_upd = acc + 12;
+    float *sh_cost = reinterpret_cast<float *>(sh_upd + 5);
+
+    const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
+    float p2x = init[2 * i], p2y = init[2 * i + 1];
+    if (!a.status_in[i]) {  // :173 (block-uniform)
+        if (tid == 0) write_outputs(a, i, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
+        return;
+    }
+    float A00 = 1, A01 = 0, A10 = 0, A11 = 1;
+    if (a.use_affine) {
+        A00 = a.affine[4 * i], A01 = a.affine[4 * i + 1], A10 = a.affine[4 * i + 2], A11 = a.affine[4 * i + 3];
+    }
+    const float refx = a.pt_ref[2 * i], refy = a.pt_ref[2 * i + 1];
+
+    // lane -> pixel map, fixed for the whole kernel: p = tid + 256 r, row-major (y outer, :233-234)
+    float px[NR], py[NR], wx[NR], wy[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        int p = tid + kBlock * r;
+        int yy = p / Wd, xx = p - yy * Wd;
+        int x = xx - h, y = yy - h;
+        px[r] = (float)x;
+        py[r] = (float)y;
+        if (a.use_affine) {  // :203-204  A(0,0)*x + A(0,1)*y, int -> float
+            wx[r] = A00 * (float)x + A01 * (float)y;
+            wy[r] = A10 * (float)x + A11 * (float)y;
+        } else {
+            wx[r] = (float)x;
+            wy[r] = (float)y;
+        }
+    }
+    // extent of the warped patch, for the interior (clamp-free) fast path
+    const float fh = (float)h;
+    const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
+    const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
+
+    int succ = 1, iters = 0;
+    float lastCost = 0.0f;
+
+    for (int level = a.n_levels - 1; level >= 0; level--) {
+        const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
+        const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
+        float nx, ny;
+        if (level == a.n_levels - 1) {  // :180
+            nx = p2x * a.scales[level];
+            ny = p2y * a.scales[level];
+        } else {  // :182
+            nx = (float)((double)(p2x * 1.0f) / 0.5);
+            ny = (float)((double)(p2y * 1.0f) / 0.5);
+        }
+        float dx = nx - ptx, dy = ny - pty, dg = 0.0f, db = 0.0f;  // :186-191
+        lastCost = 0.0f;                                            // :193
+        succ = 1;                                                   // :194
+
+        // img1 samples are iteration-invariant: once per level (bit-identical to :253, :263)
+        const float cneg = -sample<true>(L1, ptx, pty);
+        const double cd = (double)cneg;
+        float s1[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) s1[r] = sample<true>(L1, ptx + px[r], pty + py[r]);
+
+        bool h22_pending = true;
+        for (int iter = 0; iter < a.iterations; iter++) {  // :215
+            iters++;
+            // ---- sampling: all lanes, exact products into LDS -------------------------------
+            const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
+            const float gain = 1.0f + dg;
+            // interior test (block-uniform): every tap coordinate of every pixel, +-1 included,
+            // lies in [0, cols-1) x [0, rows-1) => clamps are no-ops and can be skipped.
+            const bool interior = (bx - ext_x >= 0.0f) && (bx + ext_x < L2.fcols_m1) &&
+                                  (by - ext_y >= 0.0f) && (by + ext_y < L2.frows_m1);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                int p = tid + kBlock * r;
+                if (p < P) {
+                    float X = bx + wx[r], Y = by + wy[r];
+                    Five s = interior ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
+                    float e = s.c + db - gain * s1[r];   // :252-253
+                    float Ix = 0.5f * (s.xp - s.xm);     // :259-260
+                    float Iy = 0.5f * (s.yp - s.ym);     // :261-262
+                    double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
+                    prod[0 * PP + p] = dIx * dIx;   // H00
+                    prod[1 * PP + p] = dIy * dIx;   // H10
+                    prod[2 * PP + p] = dIy * dIy;   // H11
+                    prod[3 * PP + p] = cd * dIx;    // H20
+                    prod[4 * PP + p] = cd * dIy;    // H21
+                    prod[5 * PP + p] = dIx;         // H30 = 1.0 * Ix
+                    prod[6 * PP + p] = dIy;         // H31
+                    prod[7 * PP + p] = (-dIx) * de;  // b0  (:293  -J * e)
+                    prod[8 * PP + p] = (-dIy) * de;  // b1
+                    prod[9 * PP + p] = (-cd) * de;   // b2
+                    prod[10 * PP + p] = -de;         // b3 = (-1.0) * e
+                    esq[p] = e * e;                  // :294
+                }
+            }
+            __syncthreads();
+            // ---- ordered accumulation: one lane per entry, row-major pixel order (:284-299) ---
+            if (wave == 0) {
+                if (lane < kChains) {
+                    const double *src = prod + (size_t)lane * PP;
+                    double s = 0.0;
+#pragma unroll 8
+                    for (int k = 0; k < P; k++) s += src[k];
+                    acc[lane] = s;
+                }
+            } else if (wave == 1) {
+                if (lane == 0) {
+                    float c = 0.0f;  // :283
+#pragma unroll 8
+                    for (int k = 0; k < P; k++) c += esq[k];
+                    sh_cost[0] = c;
+                }
+            } else if (wave == 2) {
+                if (lane == 0 && h22_pending) {  // H22 = sum of c*c: iteration-invariant
+                    double cc = cd * cd, s = 0.0;
+                    for (int k = 0; k < P; k++) s += cc;
+                    acc[11] = s;
+                }
+            }
+            h22_pending = false;
+            __syncthreads();
+            // ---- solve (:302-319) ------------------------------------------------------------
+            if (tid == 0) {
+                double H[4][4], b[4], upd[4];
+                H[0][0] = acc[0];
+                H[1][0] = acc[1];
+                H[1][1] = acc[2];
+                H[2][0] = acc[3];
+                H[2][1] = acc[4];
+                H[2][2] = acc[11];
+                H[3][0] = acc[5];
+                H[3][1] = acc[6];
+                H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
+                H[3][3] = (double)P;       // sum of 1.0*1.0
+                b[0] = acc[7];
+                b[1] = acc[8];
+                b[2] = acc[9];
+                b[3] = acc[10];
+                float cost = sh_cost[0];
+                if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+                double unorm = llt4_solve_norm(H, b, upd);
+                sh_upd[0] = upd[0];
+                sh_upd[1] = upd[1];
+                sh_upd[2] = upd[2];
+                sh_upd[3] = upd[3];
+                sh_upd[4] = unorm;
+                sh_cost[1] = cost;
+            }
+            __syncthreads();
+            // ---- update + termination, identically in every lane (:322-344) -------------------
+            const double u0 = sh_upd[0], u1 = sh_upd[1], u2 = sh_upd[2], u3 = sh_upd[3], unorm = sh_upd[4];
+            const float cost = sh_cost[1];
+            if (u0 != u0) {  // :322
+                succ = 0;
+                break;
+            }
+            if (iter > 0 && cost > lastCost) break;  // :328
+            dx = (float)((double)dx + u0);           // :332
+            dy = (float)((double)dy + u1);
+            if (a.illum) {  // :334-337
+                dg = (float)((double)dg + u2);
+                db = (float)((double)db + u3);
+            }
+            lastCost = cost;  // :339
+            succ = 1;
+            if (unorm < 1e-2) break;  // :343
+        }
+        p2x = ptx + dx;  // :348
+        p2y = pty + dy;
+        // the next level's first sampling pass overwrites prod/esq: every lane left the loop
+        // after the same barrier, so no extra barrier is needed here.
+    }
+    if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, 1.0f, iters);
+}
+
+}  // namespace pagk
