@@ -43,6 +43,7 @@ struct TrackArgs {
     double *dist_pred;
     float *ncc;
     int *iters;
+    unsigned long long *dbg;  // diagnostic builds only (PAGK_STAMPS)
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

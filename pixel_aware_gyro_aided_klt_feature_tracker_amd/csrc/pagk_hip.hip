@@ -188,6 +188,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.dist_pred = o->dist_pred;
     a.ncc = o->ncc;
     a.iters = o->iters;
+#ifdef PAGK_STAMPS
+    a.dbg = reinterpret_cast<unsigned long long *>(getenv("PAGK_DBG_PTR") ? strtoull(getenv("PAGK_DBG_PTR"), nullptr, 0) : 0ull);
+#endif
     a.half = p->half_patch;
     a.iterations = p->iterations;
     a.has_gyro = p->has_gyro_predict_initial;
@@ -215,7 +218,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
         } else {
             const int P = (2 * a.half + 1) * (2 * a.half + 1);
-            const int nr = (P + kBlock - 1) / kBlock;
+            const int nr = (P + kBlock - 1) / kBlock, tail = P % 32;
             const size_t lds = track_block_lds_bytes(a.half);
             auto launch = [&](auto kern) -> hipError_t {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -224,12 +227,21 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 hipLaunchKernelGGL(kern, dim3(n), dim3(kBlock), lds, ctx->stream, a);
                 return hipGetLastError();
             };
-            hipError_t e;
-            switch (nr) {
-                case 1: e = launch(k_track_block<1>); break;
-                case 2: e = launch(k_track_block<2>); break;
-                case 3: e = launch(k_track_block<3>); break;
-                default: e = launch(k_track_block<4>); break;
+            // (NR, TAIL) for h = 1..15: P = (2h+1)^2 is an odd square, so P mod 32 is 1, 9, 17 or 25
+            hipError_t e = hipErrorInvalidValue;
+            switch (nr * 100 + tail) {
+                case 101: e = launch(k_track_block<1, 1>); break;    // h = 7
+                case 109: e = launch(k_track_block<1, 9>); break;    // h = 1, 6
+                case 117: e = launch(k_track_block<1, 17>); break;   // h = 3, 4
+                case 125: e = launch(k_track_block<1, 25>); break;   // h = 2, 5
+                case 201: e = launch(k_track_block<2, 1>); break;    // h = 8
+                case 209: e = launch(k_track_block<2, 9>); break;    // h = 9
+                case 225: e = launch(k_track_block<2, 25>); break;   // h = 10
+                case 317: e = launch(k_track_block<3, 17>); break;   // h = 11, 12
+                case 325: e = launch(k_track_block<3, 25>); break;   // h = 13
+                case 409: e = launch(k_track_block<4, 9>); break;    // h = 14
+                case 401: e = launch(k_track_block<4, 1>); break;    // h = 15
+                default: break;
             }
             HIPCHK(ctx, e);
         }

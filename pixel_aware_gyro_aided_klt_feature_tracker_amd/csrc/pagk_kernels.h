@@ -12,10 +12,11 @@
 // f64 (f32 for cost) additions per entry per iteration.  That chain is the critical path of a
 // feature.  The kernel keeps it as short as the hardware allows: all 256 lanes sample the patch
 // and form the EXACT f64 products (24-bit x 24-bit fits 53 bits, so the product and
-// multiply-add orders agree), stage them in LDS, and then one lane per accumulator entry walks
-// its array with one ds_read_b64 + one v_add_f64 per pixel.
+// multiply-add orders agree), stage them in LDS, and then one 16-lane DPP row per accumulator entry
+// walks its stream at the dependent-FMA latency (5.9 cycles per pixel, pagk_chain_asm.h).
 #pragma once
 #include "pagk_device.h"
+#include "pagk_chain_asm.h"
 
 namespace pagk {
 
@@ -164,36 +165,53 @@ __global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
 }
 
 // ---- one workgroup per feature -----------------------------------------------------------------
-// NR = ceil((2h+1)^2 / 256): pixels per lane.  Dynamic LDS:
-//   double prod[11][PP]   exact f64 products, one array per accumulator entry, PP = P rounded
-//                         up to even.  Entry order: H00 H10 H11 H20 H21 H30 H31 b0 b1 b2 b3
-//   float  esq[PP]        f32-rounded e*e (the `cost` chain, :294)
-//   double acc[12]        chain results (acc[11] = H22)
-//   double upd[5]         update[0..3], norm
-//   float  costs[2], int flags
+// 256 threads = 4 waves.  Per Gauss-Newton iteration:
+//   1. sampling  -- every lane owns NR = ceil(P/256) pixels of the patch; for each it takes the five
+//                   img2 samples, forms e, Ix, Iy (f32, :252-262) and stores to LDS the eight f64
+//                   streams the accumulator entries need (three squares/cross products of the
+//                   gradient, Ix*e, Iy*e, and Ix, Iy, e widened) plus the f32 stream e*e;
+//   2. ordered accumulation -- 16 DPP rows (4 per wave), one per entry: H00 H10 H11 b0 | b1 H20 H21
+//                   H30 | H31 b2 b3 H22 | cost (f32, wave 3).  Entries with a constant second
+//                   factor (c or 1) multiply it in the FMA: fma(Ix, c, H20) == H20 + c*Ix because
+//                   the product of two f32-valued doubles is exact.  pagk_chain_asm.h;
+//   3. solve     -- one lane: penalty, 4x4 LLT, two triangular solves, norm;
+//   4. update    -- every lane applies the same update and takes the same exit (:322-343).
+// Dynamic LDS: double stream[8][PP]; float esq[PP]; double cslot[2]; double acc[16];
+//              double upd[5]; float cost[2]      with PP = 32 * ceil(P / 32).
 constexpr int kBlock = 256;
-constexpr int kChains = 11;
+constexpr int kStreams = 8;
 
-__host__ __device__ inline size_t track_block_lds_bytes(int half)
+__host__ __device__ inline int track_block_pp(int half)
 {
     int P = (2 * half + 1) * (2 * half + 1);
-    int PP = (P + 1) & ~1;
-    return (size_t)kChains * PP * 8 + (size_t)PP * 4 + 12 * 8 + 5 * 8 + 16;
+    return (P + 31) / 32 * 32;
+}
+__host__ __device__ inline size_t track_block_lds_bytes(int half)
+{
+    size_t PP = (size_t)track_block_pp(half);
+    return kStreams * PP * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;
 }
 
-template <int NR>
+__device__ __forceinline__ uint32_t lds_off(const void *p)
+{
+    return (uint32_t)(uintptr_t)p;  // low half of a flat LDS address = offset in the LDS aperture
+}
+
+template <int NR, int TAIL>
 __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int i = blockIdx.x;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = (P + 1) & ~1;
+    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
+    const int nfull = P / 32;  // P mod 32 == TAIL
 
-    double *prod = reinterpret_cast<double *>(lds_raw);
-    float *esq = reinterpret_cast<float *>(prod + (size_t)kChains * PP);
-    double *acc = reinterpret_cast<double *>(esq + PP);
-    double *sh_upd = acc + 12;
+    double *stream = reinterpret_cast<double *>(lds_raw);
+    float *esq = reinterpret_cast<float *>(stream + (size_t)kStreams * PP);
+    double *cslot = reinterpret_cast<double *>(esq + PP);
+    double *acc = cslot + 2;
+    double *sh_upd = acc + 16;
     float *sh_cost = reinterpret_cast<float *>(sh_upd + 5);
 
     const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
@@ -230,10 +248,43 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
     const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
 
+    // accumulator row of this lane: entry id, its LDS stream, block stride
+    const int lr = lane & 15;
+    const int cid = wave * 4 + (lane >> 4);
+    // entry:        0    1    2    3    4    5    6    7    8    9    10   11(H22)
+    // stream:       XX   YX   YY   XE   YE   X    Y    X    Y    E    E    cslot
+    const int stream_of[12] = {0, 1, 2, 3, 4, 5, 6, 5, 6, 7, 7, 0};
+    uint32_t row_addr, row_inc;
+    if (cid < 11) {
+        row_addr = lds_off(stream + (size_t)stream_of[cid] * PP) + 16u * lr;
+        row_inc = 256u;
+    } else if (cid == 11) {
+        row_addr = lds_off(cslot);  // every lane re-reads (c, c)
+        row_inc = 0u;
+    } else {
+        row_addr = lds_off(esq) + 8u * lr;
+        row_inc = 128u;
+    }
+
     int succ = 1, iters = 0;
     float lastCost = 0.0f;
+#ifdef PAGK_STAMPS
+    // diagnostic build only: cycles per phase, summed over iterations, written to a.dbg (a buffer
+    // nothing else reads).  [0] level setup, [1] sampling, [2] chains, [3] solve, [4] update, [5] total
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_begin = __builtin_amdgcn_s_memtime(), t0, t1;
+#define STAMP(k)                                  \
+    t1 = __builtin_amdgcn_s_memtime();            \
+    st[k] += t1 - t0;                             \
+    t0 = t1;
+#else
+#define STAMP(k)
+#endif
 
     for (int level = a.n_levels - 1; level >= 0; level--) {
+#ifdef PAGK_STAMPS
+        t0 = __builtin_amdgcn_s_memtime();
+#endif
         const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
         const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
         float nx, ny;
@@ -254,11 +305,23 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
         float s1[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) s1[r] = sample<true>(L1, ptx + px[r], pty + py[r]);
+        // second FMA factor of this lane's row (:264  J = (Ix, Iy, de_dg, 1))
+        double row_s1;
+        switch (cid) {
+            case 3: case 4: case 10: row_s1 = -1.0; break;  // b0 b1 b3:  -J * e
+            case 5: case 6: case 11: row_s1 = cd; break;     // H20 H21 H22
+            case 9: row_s1 = -cd; break;                     // b2
+            default: row_s1 = 1.0; break;
+        }
+        if (tid == 0) {
+            cslot[0] = cd;
+            cslot[1] = cd;
+        }
 
-        bool h22_pending = true;
+        STAMP(0)
         for (int iter = 0; iter < a.iterations; iter++) {  // :215
             iters++;
-            // ---- sampling: all lanes, exact products into LDS -------------------------------
+            // ---- 1. sampling ------------------------------------------------------------------
             const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
             const float gain = 1.0f + dg;
             // interior test (block-uniform): every tap coordinate of every pixel, +-1 included,
@@ -275,61 +338,44 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
                     float Ix = 0.5f * (s.xp - s.xm);     // :259-260
                     float Iy = 0.5f * (s.yp - s.ym);     // :261-262
                     double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
-                    prod[0 * PP + p] = dIx * dIx;   // H00
-                    prod[1 * PP + p] = dIy * dIx;   // H10
-                    prod[2 * PP + p] = dIy * dIy;   // H11
-                    prod[3 * PP + p] = cd * dIx;    // H20
-                    prod[4 * PP + p] = cd * dIy;    // H21
-                    prod[5 * PP + p] = dIx;         // H30 = 1.0 * Ix
-                    prod[6 * PP + p] = dIy;         // H31
-                    prod[7 * PP + p] = (-dIx) * de;  // b0  (:293  -J * e)
-                    prod[8 * PP + p] = (-dIy) * de;  // b1
-                    prod[9 * PP + p] = (-cd) * de;   // b2
-                    prod[10 * PP + p] = -de;         // b3 = (-1.0) * e
-                    esq[p] = e * e;                  // :294
+                    stream[0 * PP + p] = dIx * dIx;
+                    stream[1 * PP + p] = dIy * dIx;
+                    stream[2 * PP + p] = dIy * dIy;
+                    stream[3 * PP + p] = dIx * de;
+                    stream[4 * PP + p] = dIy * de;
+                    stream[5 * PP + p] = dIx;
+                    stream[6 * PP + p] = dIy;
+                    stream[7 * PP + p] = de;
+                    esq[p] = e * e;  // :294
                 }
             }
             __syncthreads();
-            // ---- ordered accumulation: one lane per entry, row-major pixel order (:284-299) ---
-            if (wave == 0) {
-                if (lane < kChains) {
-                    const double *src = prod + (size_t)lane * PP;
-                    double s = 0.0;
-#pragma unroll 8
-                    for (int k = 0; k < P; k++) s += src[k];
-                    acc[lane] = s;
-                }
-            } else if (wave == 1) {
-                if (lane == 0) {
-                    float c = 0.0f;  // :283
-#pragma unroll 8
-                    for (int k = 0; k < P; k++) c += esq[k];
-                    sh_cost[0] = c;
-                }
-            } else if (wave == 2) {
-                if (lane == 0 && h22_pending) {  // H22 = sum of c*c: iteration-invariant
-                    double cc = cd * cd, s = 0.0;
-                    for (int k = 0; k < P; k++) s += cc;
-                    acc[11] = s;
-                }
+            STAMP(1)
+            // ---- 2. ordered accumulation (:284-299) -------------------------------------------
+            if (wave < 3) {
+                double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
+                if (lr == 0) acc[cid] = s;
+            } else {
+                float c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
+                if (lane == 0) sh_cost[0] = c;
             }
-            h22_pending = false;
             __syncthreads();
-            // ---- solve (:302-319) ------------------------------------------------------------
+            STAMP(2)
+            // ---- 3. solve (:302-319) ------------------------------------------------------------
             if (tid == 0) {
                 double H[4][4], b[4], upd[4];
                 H[0][0] = acc[0];
                 H[1][0] = acc[1];
                 H[1][1] = acc[2];
-                H[2][0] = acc[3];
-                H[2][1] = acc[4];
+                H[2][0] = acc[5];
+                H[2][1] = acc[6];
                 H[2][2] = acc[11];
-                H[3][0] = acc[5];
-                H[3][1] = acc[6];
+                H[3][0] = acc[7];
+                H[3][1] = acc[8];
                 H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
                 H[3][3] = (double)P;       // sum of 1.0*1.0
-                b[0] = acc[7];
-                b[1] = acc[8];
+                b[0] = acc[3];
+                b[1] = acc[4];
                 b[2] = acc[9];
                 b[3] = acc[10];
                 float cost = sh_cost[0];
@@ -343,7 +389,8 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
                 sh_cost[1] = cost;
             }
             __syncthreads();
-            // ---- update + termination, identically in every lane (:322-344) -------------------
+            STAMP(3)
+            // ---- 4. update + termination, identically in every lane (:322-344) -----------------
             const double u0 = sh_upd[0], u1 = sh_upd[1], u2 = sh_upd[2], u3 = sh_upd[3], unorm = sh_upd[4];
             const float cost = sh_cost[1];
             if (u0 != u0) {  // :322
@@ -363,10 +410,19 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
         }
         p2x = ptx + dx;  // :348
         p2y = pty + dy;
-        // the next level's first sampling pass overwrites prod/esq: every lane left the loop
-        // after the same barrier, so no extra barrier is needed here.
+        // the next level's first sampling pass overwrites the streams: every lane left the loop
+        // after the same barrier, and cslot is rewritten before the next pass's first barrier.
     }
     if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, 1.0f, iters);
+#ifdef PAGK_STAMPS
+    if (tid == 0 && a.dbg) {
+        st[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int k = 0; k < 6; k++) a.dbg[(size_t)i * 8 + k] = st[k];
+        a.dbg[(size_t)i * 8 + 6] = (unsigned long long)iters;
+        a.dbg[(size_t)i * 8 + 7] = t_begin;
+    }
+#endif
+#undef STAMP
 }
 
 }  // namespace pagk

@@ -1,0 +1,81 @@
+"""Feature sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The path shards by independent units: a feature's Gauss-Newton loop reads only the two
+(replicated, read-only) pyramids and its own 33 bytes of input (reference
+src/patch_match.cpp:167-367).  Rank r takes the contiguous index block
+[r*ceil(n/G), min(n, (r+1)*ceil(n/G))), so index order -- and with it the order of the
+tracker's f64 mean-pixel-error sum (src/gyro_aided_tracker.cpp:297-304) -- is the same as
+on one GPU.  The only exchange is one all-gather of the packed per-rank result slice
+(37 bytes per feature + 4 for the diagnostic iteration count); backend "nccl" is RCCL over
+xGMI on ROCm, "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# (name, torch dtype, elements per feature) in SetMatcher order (src/patch_match.cpp:370-388)
+FIELDS = (("pt_un", torch.float32, 2), ("pt_dist", torch.float32, 2), ("status", torch.uint8, 1),
+          ("pix_err", torch.float64, 1), ("dist_pred", torch.float64, 1), ("ncc", torch.float32, 1),
+          ("iters", torch.int32, 1))
+BYTES_PER_FEATURE = sum(torch.empty(0, dtype=dt).element_size() * k for _, dt, k in FIELDS)  # 41
+
+
+def shard_size(n: int, world: int) -> int:
+    return (n + world - 1) // world
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    m = shard_size(n, world)
+    lo = min(n, rank * m)
+    return lo, min(n, lo + m)
+
+
+def alloc_device_outputs(m: int, device) -> dict:
+    """Per-rank output arrays for pagk_track_device, carved out of ONE byte buffer so that
+    the all-gather ships a single contiguous slice.  SoA blocks, each 8-byte aligned."""
+    m = max(m, 1)
+    offs, total = {}, 0
+    for name, dt, k in FIELDS:
+        offs[name] = total
+        total += (torch.empty(0, dtype=dt).element_size() * k * m + 7) // 8 * 8
+    buf = torch.zeros(total, dtype=torch.uint8, device=device)
+    out = {"_buf": buf, "_m": m}
+    for name, dt, k in FIELDS:
+        nbytes = torch.empty(0, dtype=dt).element_size() * k * m
+        v = buf[offs[name]:offs[name] + nbytes].view(dt)
+        out[name] = v.view(m, k) if k > 1 else v
+    return out
+
+
+def views_of(buf: torch.Tensor, m: int) -> dict:
+    """Typed views into one rank's packed slice (inverse of alloc_device_outputs)."""
+    out, off = {}, 0
+    for name, dt, k in FIELDS:
+        nbytes = torch.empty(0, dtype=dt).element_size() * k * m
+        v = buf[off:off + nbytes].view(dt)
+        out[name] = v.view(m, k) if k > 1 else v
+        off += (nbytes + 7) // 8 * 8
+    return out
+
+
+def all_gather_results(local: dict, n: int, group=None) -> dict:
+    """One all-gather of every rank's packed slice; returns full-length (n) tensors on every
+    rank, in feature-index order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    m = local["_m"]
+    if world == 1:
+        return {name: local[name][:n] for name, _, _ in FIELDS}
+    buf = local["_buf"]
+    gathered = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    parts = [views_of(gathered[r * buf.numel():(r + 1) * buf.numel()], m) for r in range(world)]
+    full = {}
+    for name, _, _ in FIELDS:
+        full[name] = torch.cat([p[name] for p in parts], dim=0)[:n]
+    return full
+
+
+def to_numpy(full: dict) -> dict:
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in full.items()}

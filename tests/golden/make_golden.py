@@ -1,0 +1,85 @@
+"""Generates the committed golden vectors under tests/golden/.
+
+What these fixtures pin: the CPU oracle's own outputs (oracle/pagk_oracle.c) on small seeded
+cases, one per flag / edge-case combination of the path.  They guard the oracle against
+regressions and give the GPU tests fixed expected outputs.  They do NOT pin the oracle to the
+reference: the reference cannot be built here and ships no vectors (PARITY UNPINNED, see
+oracle/pagk_oracle.h).  Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import pagk_oracle as orc  # noqa: E402
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth  # noqa: E402
+
+CASES = []
+
+
+def case(name, w, **flags):
+    CASES.append((name, w, flags))
+
+
+def base(seed, **kw):
+    kw.setdefault("half_patch", 5)
+    kw.setdefault("iterations", 10)
+    kw.setdefault("pyramids", 3)
+    return synth.make_workload("g", 160, 120, 64, seed=seed, camera=synth.D435I, omega=(0.2, -0.3, 0.8), **kw)
+
+
+# flag combinations of GyroAidedTracker::eType (reference src/gyro_aided_tracker.cpp:384-408)
+for i, (aff, ill, pen) in enumerate([(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]):
+    case(f"flags_a{aff}_i{ill}_p{pen}", base(0x601D0000 + i), affine=bool(aff), illumination=bool(ill),
+         penalty=bool(pen))
+# BASELINE-shaped patch / iteration counts
+case("h10_it30_L3", base(0x601D0100, half_patch=10, iterations=30))
+case("h10_it30_L4", synth.make_workload("g", 320, 240, 64, seed=0x601D0101, half_patch=10, iterations=30, pyramids=4,
+                                        camera=synth.D435I, omega=(0.2, -0.3, 0.8)))
+case("h7_L2", base(0x601D0102, half_patch=7, pyramids=2))
+case("L1", base(0x601D0103, pyramids=1))
+# identity initial guess (the !mbHasGyroPredictInitial branch, :264-270) incl. the penalty NaN case (H7)
+case("identity_init", synth.make_workload("g", 160, 120, 64, seed=0x601D0104, half_patch=5, iterations=10,
+                                          pyramids=3, motion="translation", has_gyro=False))
+case("identity_init_penalty", synth.make_workload("g", 160, 120, 64, seed=0x601D0105, half_patch=5, iterations=10,
+                                                  pyramids=3, motion="translation", has_gyro=False), penalty=True)
+# features hugging the border (clamped taps, linear-address wrap at the right/bottom edge)
+case("edge_features", base(0x601D0106, edge_fraction=1.0))
+# some features switched off by the producer (status_in = 0)
+w = base(0x601D0107)
+w.status_in[::3] = 0
+case("status_in_zero", w)
+# flat patches: black image region -> H singular -> NaN -> status 0 (:322-326)
+w = base(0x601D0108)
+w.img_ref[:60, :] = 0
+w.img_cur[:60, :] = 0
+case("flat_region", w)
+# saturated region
+w = base(0x601D0109)
+w.img_ref[:, :80] = 255
+w.img_cur[:, :80] = 255
+case("saturated_region", w)
+
+
+def main():
+    for name, w, flags in CASES:
+        p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids,
+                             has_gyro=w.has_gyro, camera=w.camera,
+                             illumination=flags.get("illumination", True), affine=flags.get("affine", True),
+                             penalty=flags.get("penalty", False))
+        out = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=1)
+        cam = np.array([w.camera.fx, w.camera.fy, w.camera.cx, w.camera.cy, *w.camera.dist[:4]], np.float64)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            img_ref=w.img_ref, img_cur=w.img_cur, pt_ref=w.pt_ref, pt_init=w.pt_init, affine=w.affine,
+            status_in=w.status_in, camera=cam,
+            cfg=np.array([w.half_patch, w.iterations, w.pyramids, int(w.has_gyro), int(flags.get("illumination", True)),
+                          int(flags.get("affine", True)), int(flags.get("penalty", False))], np.int32),
+            **{"out_" + k: v[:w.n] for k, v in out.items()})
+        print(f"{name}: n={w.n} ok={int(out['status'][:w.n].sum())} mean iters {out['iters'][:w.n].mean():.2f}")
+
+
+if __name__ == "__main__":
+    main()

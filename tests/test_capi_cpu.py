@@ -1,0 +1,84 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/pagk.h
+declares, and its host-side entry points behave.  No compute calls need a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pagk_oracle as orc
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "pagk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pagk_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = capi.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+
+
+def test_version_errors_defaults(built):
+    lib = capi.load()
+    assert lib.pagk_version() == 100
+    assert lib.pagk_strerror(0) == b"ok" and lib.pagk_strerror(-4) == b"unsupported mode"
+    p = capi.Params()
+    lib.pagk_params_default(C.byref(p))
+    # reference call site src/gyro_aided_tracker.cpp:276-282 + eType 4 (:402-408) + ctor constants
+    assert (p.half_patch, p.iterations, p.pyramids) == (5, 10, 3)
+    assert (p.has_gyro_predict_initial, p.inverse, p.consider_illumination, p.consider_affine,
+            p.regularization_penalty, p.calculate_ncc) == (1, 0, 1, 1, 0, 0)
+    assert (p.lambda_, p.alpha, p.max_distance) == (1.0, 0.5, 25)
+    assert lib.pagk_inv_log_max_dist(0.5, 25) == orc.load().pagk_oracle_inv_log_max_dist(0.5, 25)
+
+
+def test_struct_layout_matches_header(built):
+    # the ctypes mirror must have the C layout (a mismatch would silently corrupt every call)
+    assert C.sizeof(capi.Image) == 24
+    assert C.sizeof(capi.Outputs) == 7 * 8
+    assert capi.Params.fx.offset == 36 and capi.Params.n_dist_coef.offset == 72 and C.sizeof(capi.Params) == 76
+
+
+def test_post_filter_matches_oracle(built):
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 257):
+        status = (rng.random(n) < 0.8).astype(np.uint8)
+        err = rng.random(n) * 12
+        dist = rng.random(n) * 30
+        pt = rng.random((n, 2)).astype(np.float32)
+        a = capi.post_filter(5, status, err, dist, pt, pt + 1)
+        b = orc.post_filter(5, status, err, dist, pt, pt + 1)
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
+
+
+def test_create_without_device_fails_loudly(built):
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.pagk_create(C.byref(h), 0) == capi.PAGK_E_NODEVICE
+    with pytest.raises(capi.PagkError):
+        capi.Context(0)
+
+
+def test_missing_library_is_an_error(built, monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libpagk_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load()
+
+
+def test_synth_is_deterministic():
+    a, b = synth.config(1, n=50), synth.config(1, n=50)
+    assert np.array_equal(a.img_cur, b.img_cur) and np.array_equal(a.pt_init, b.pt_init)
+    assert np.array_equal(a.affine, b.affine)
+    assert synth.SplitMix64(1).next_u64() == 0x910A2DEC89025CC1

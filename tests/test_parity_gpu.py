@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors.  Bar (BASELINE.json north_star): status masks bit-exact, tracked
+coordinates within 1e-3 px.  The kernels reproduce the CPU arithmetic operation for operation,
+so these tests also assert bit-identical outputs (exact=True); if a future kernel trades that
+for speed, relax `exact` here -- never PT_TOL."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pagk_oracle as orc
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
+
+from util import assert_parity, golden_cases, load_golden, params_for
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(ctx, p, w, kernel=0, nthreads=16):
+    ctx.set_kernel(kernel)
+    got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    ctx.set_kernel(0)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=nthreads)
+    return got, ref
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_hip_matches_golden_vectors(ctx, name):
+    params, inp, exp = load_golden(name)
+    got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                    inp["status_in"])
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("name", ["h10_it30_L3", "edge_features", "flat_region", "flags_a1_i1_p1"])
+def test_thread_kernel_matches_golden_vectors(ctx, name):
+    # the reference-shaped one-thread-per-feature kernel: an independent device implementation
+    params, inp, exp = load_golden(name)
+    ctx.set_kernel(1)
+    try:
+        got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                        inp["status_in"])
+    finally:
+        ctx.set_kernel(0)
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("idx,n", [(0, 500), (1, 1000), (2, 2000), (3, 3000)])
+def test_baseline_configs_against_oracle(ctx, idx, n):
+    # BASELINE.json configs (synthetic stand-ins); 21x21 patch, 30 iterations
+    w = synth.config(idx, n=n)
+    p = params_for(w)
+    got, ref = run_both(ctx, p, w)
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+    act = w.status_in > 0
+    assert ref["status"][:w.n][act].mean() > 0.95
+    # the tracker-side inlier mask (src/gyro_aided_tracker.cpp:289-341) must be bit-exact too
+    a = capi.post_filter(w.half_patch, got["status"][:w.n], got["pix_err"][:w.n], got["dist_pred"][:w.n],
+                         got["pt_dist"][:w.n], got["pt_un"][:w.n])
+    b = orc.post_filter(w.half_patch, ref["status"][:w.n], ref["pix_err"][:w.n], ref["dist_pred"][:w.n],
+                        ref["pt_dist"][:w.n], ref["pt_un"][:w.n])
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15])
+def test_every_patch_size(ctx, h):
+    # every (NR, TAIL) instantiation of k_track_block
+    w = synth.make_workload(f"h{h}", 320, 240, 48, seed=0x5EED0100 + h, half_patch=h, iterations=12, pyramids=3,
+                            camera=synth.D435I)
+    got, ref = run_both(ctx, params_for(w), w, nthreads=8)
+    assert_parity(got, ref, w.n, exact=True, what=f"h={h}")
+
+
+@pytest.mark.parametrize("L,it", [(1, 10), (2, 1), (3, 0), (5, 10)])
+def test_levels_and_iteration_counts(ctx, L, it):
+    w = synth.make_workload("lv", 320, 256, 40, seed=0x5EED0200 + L, half_patch=5, iterations=it, pyramids=L)
+    got, ref = run_both(ctx, params_for(w), w, nthreads=4)
+    assert_parity(got, ref, w.n, exact=True, what=f"L={L} it={it}")
+
+
+def test_empty_and_all_skipped(ctx):
+    w = synth.make_workload("e", 160, 120, 16, seed=0x5EED0300, half_patch=5, iterations=10, pyramids=3)
+    p = params_for(w)
+    out = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref[:0], w.pt_init[:0], w.affine[:0], w.status_in[:0])
+    assert out["status"].shape[0] == 1  # n = 0: nothing written, no error
+    st0 = np.zeros_like(w.status_in)
+    got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, st0)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, st0)
+    assert_parity(got, ref, w.n, exact=True)
+    assert not got["status"][:w.n].any() and np.array_equal(got["pt_un"][:w.n], w.pt_init)
+
+
+def test_non_contiguous_rows(ctx):
+    # cv::Mat with step > cols (an ROI): the bytes between cols and step are defined as 0
+    w = synth.make_workload("roi", 200, 120, 40, seed=0x5EED0400, half_patch=5, iterations=10, pyramids=2,
+                            edge_fraction=0.5)
+    big_r = np.full((120, 256), 77, np.uint8)
+    big_c = np.full((120, 256), 77, np.uint8)
+    big_r[:, :200] = w.img_ref
+    big_c[:, :200] = w.img_cur
+    vr, vc = big_r[:, :200], big_c[:, :200]
+    p = params_for(w)
+    got = ctx.track(p, vr, vc, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    ref = orc.track(p, vr, vc, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert_parity(got, ref, w.n, exact=True)
+
+
+def test_pyramid_levels_match_oracle(ctx):
+    w = synth.config(1, n=8)
+    ctx.frame_upload(0, w.img_cur, 4)
+    lvl = w.img_cur
+    for l in range(1, 4):
+        lvl = orc.pyr_down(lvl)
+        assert np.array_equal(ctx.frame_download_level(0, l, w.img_cur.shape[1], w.img_cur.shape[0]), lvl)
+
+
+def test_caller_built_pyramids(ctx):
+    w = synth.make_workload("pyr", 320, 240, 40, seed=0x5EED0500, half_patch=5, iterations=10, pyramids=3)
+    p = params_for(w)
+    ref_l, cur_l = [w.img_ref], [w.img_cur]
+    for _ in range(2):
+        ref_l.append(orc.pyr_down(ref_l[-1]))
+        cur_l.append(orc.pyr_down(cur_l[-1]))
+    got = ctx.track_pyr(p, ref_l, cur_l, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert_parity(got, ref, w.n, exact=True)
+    # a different (caller-chosen) pyramid is honoured: blur level 1 and compare with the oracle's pyr variant
+    cur_l2 = [cur_l[0], np.ascontiguousarray(np.roll(cur_l[1], 1, axis=1)), cur_l[2]]
+    got2 = ctx.track_pyr(p, ref_l, cur_l2, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    ref2 = orc.track_pyr(p, ref_l, cur_l2, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert_parity(got2, ref2, w.n, exact=True)
+
+
+def test_error_codes(ctx):
+    w = synth.make_workload("err", 160, 120, 8, seed=0x5EED0600, half_patch=5, iterations=10, pyramids=3)
+    for bad in (dict(inverse=True), dict(ncc=True)):
+        p = capi.make_params(half_patch=5, iterations=10, pyramids=3, **bad)
+        with pytest.raises(capi.PagkError) as e:
+            ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert e.value.code == capi.PAGK_E_UNSUPPORTED
+    p = capi.make_params(half_patch=16)
+    with pytest.raises(capi.PagkError) as e:
+        ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert e.value.code == capi.PAGK_E_ARG
+    p = capi.make_params(half_patch=5, pyramids=3)
+    odd = np.zeros((121, 161), np.uint8)
+    with pytest.raises(capi.PagkError) as e:   # odd parent: only the exact-2x resize path exists
+        ctx.track(p, odd, odd, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert e.value.code == capi.PAGK_E_UNSUPPORTED
+    with pytest.raises(capi.PagkError) as e:   # size mismatch between the two frames
+        ctx.track(p, w.img_ref, w.img_cur[:100], w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert e.value.code == capi.PAGK_E_ARG
+    # the context stays usable after errors
+    got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert got["status"][:w.n].any()
+
+
+def test_device_resident_path_matches_host_path(ctx):
+    w = synth.config(1, n=600)
+    p = params_for(w)
+    host = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+    for _ in range(2):
+        out = rt.step()
+    torch.cuda.synchronize()
+    dev = distributed.to_numpy(out)
+    rt.close()
+    assert_parity(dev, host, w.n, exact=True)
+
+
+# ---- full-size properties (sizes the oracle would take too long to check in full) ---------------
+def test_full_size_properties_1080p_20000(ctx):
+    w = synth.config(3)  # 1920x1080, 20000 keypoints
+    p = params_for(w)
+    a = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    b = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    n = w.n
+    for k in a:  # determinism: bitwise identical across launches
+        assert np.array_equal(a[k][:n], b[k][:n], equal_nan=True), k
+    # permutation invariance: a feature's result does not depend on its index / workgroup
+    perm = np.random.default_rng(7).permutation(n)
+    c = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref[perm].copy(), w.pt_init[perm].copy(), w.affine[perm].copy(),
+                  w.status_in[perm].copy())
+    for k in a:
+        assert np.array_equal(a[k][:n][perm], c[k][:n], equal_nan=True), k
+    # a seeded subset checked against the oracle
+    sub = np.sort(np.random.default_rng(8).choice(n, 1500, replace=False))
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref[sub].copy(), w.pt_init[sub].copy(), w.affine[sub].copy(),
+                    w.status_in[sub].copy(), nthreads=16)
+    assert_parity({k: v[:n][sub] for k, v in a.items()}, ref, sub.size, exact=True)
+    # accuracy against the analytic ground truth
+    ok = (a["status"][:n] > 0) & (w.status_in > 0)
+    err = np.linalg.norm(a["pt_un"][:n].astype(np.float64) - w.pt_true, axis=1)[ok]
+    assert ok.sum() > 0.9 * w.n_active and np.median(err) < 0.05 and np.percentile(err, 99) < 0.5
+    # skipped features: untouched initial point, zero outputs
+    sk = w.status_in == 0
+    assert not a["status"][:n][sk].any() and np.all(a["pix_err"][:n][sk] == 0)

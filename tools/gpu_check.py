@@ -32,13 +32,24 @@ def main():
             tcpu = time.time() - t
             print(f"{w.name} n={w.n} active={w.n_active} penalty={penalty}: oracle {tcpu*1e3:.1f} ms "
                   f"({w.n_active/tcpu:.0f} feat/s), mean iters {ref['iters'][:w.n].mean():.2f}, ok {int(ref['status'].sum())}", flush=True)
-            for k in (0, 1):
+            for k in ((0, 1) if idx < 2 else (0,)):
                 ctx.set_kernel(k)
                 got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
                 got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
                 trk, pyr = ctx.last_kernel_ms()
                 print(f"  kernel {k}: track {trk*1e3:.1f} us, pyramid(last frame) {pyr*1e3:.1f} us -> {w.n_active/trk/1e3:.2f} Mfeat/s", flush=True)
                 ok &= compare(f"kernel {k} vs oracle", got, ref, w.status_in)
+    # other patch sizes: every (NR, TAIL) instantiation of k_track_block
+    for h in (1, 2, 3, 5, 6, 7, 8, 9, 11, 13, 14, 15):
+        w = synth.make_workload(f"h{h}", 320, 240, 64, seed=0x5EED0100 + h, half_patch=h, iterations=10, pyramids=3,
+                                camera=synth.D435I)
+        p = capi.make_params(half_patch=h, iterations=10, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
+        ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+        ctx.set_kernel(0)
+        got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        trk, _ = ctx.last_kernel_ms()
+        print(f"half_patch {h}: track {trk*1e3:.1f} us", flush=True)
+        ok &= compare(f"h={h} kernel 0 vs oracle", got, ref, w.status_in)
     ctx.close()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
