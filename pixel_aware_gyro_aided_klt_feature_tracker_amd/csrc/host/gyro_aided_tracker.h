@@ -1,0 +1,105 @@
+// gyro_aided_tracker.h -- the hot-path side of the reference's GyroAidedTracker
+// (include/gyro_aided_tracker.h:47-260): data constructor, TrackFeatures() type dispatch,
+// GyroPredictFeatures(), GyroPredictFeaturesAndOpticalFlowRefined() and the public result vectors
+// PatchMatch reads and writes.  Geometry validation, the unused matchers, display and logging are out
+// of scope and are not declared.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "cvlite.h"
+
+namespace IMU {
+// reference include/imu_types.h:93-107
+class Point {
+public:
+    Point() {}
+    Point(const float &acc_x, const float &acc_y, const float &acc_z, const float &ang_vel_x,
+          const float &ang_vel_y, const float &ang_vel_z, const double &timestamp)
+        : a(acc_x, acc_y, acc_z), w(ang_vel_x, ang_vel_y, ang_vel_z), t(timestamp) {}
+    cv::Point3f a, w;
+    double t = 0;
+};
+}  // namespace IMU
+
+class GyroAidedTracker {
+public:
+    enum eType {  // reference include/gyro_aided_tracker.h:55-63
+        OPENCV_OPTICAL_FLOW_PYR_LK = 0,
+        GYRO_PREDICT = 1,
+        GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED = 2,
+        GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION = 3,
+        GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION = 4,
+        GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION_REGULAR = 6,
+        IMAGE_ONLY_OPTICAL_FLOW_CONSIDER_ILLUMINATION = 5
+    };
+    enum ePredictMethod { PIXEL_AWARE_PREDICTION = 1, SINGLE_HOMOGRAPHY = 2 };
+
+    // reference include/gyro_aided_tracker.h:109-117 (the Frame-based constructor :119-126 needs
+    // Frame / IMU::Calib, which stay the host application's own types)
+    GyroAidedTracker(double t, double t_ref, const cv::Mat &imgGrayRef_, const cv::Mat &imgGrayCur_,
+                     const std::vector<cv::KeyPoint> &vKeysRef_, const std::vector<cv::KeyPoint> &vKeysCur_,
+                     const std::vector<cv::KeyPoint> &vKeysUnRef_, const std::vector<cv::KeyPoint> &vKeysUnCur_,
+                     const std::vector<IMU::Point> &vImuFromLastFrame, const cv::Point3f &bias_, cv::Mat K_,
+                     cv::Mat DistCoef_, const cv::Mat &normalizeTable_,
+                     eType type_ = GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION,
+                     ePredictMethod predictMethod_ = PIXEL_AWARE_PREDICTION, std::string saveFolderPath = "",
+                     int halfPatchSize_ = 5);
+
+    void Initialize();
+    void SetRegularizationPenalty(bool flag) { mbRegularizationPenalty = flag; }
+    int TrackFeatures();
+    void SetRcl(const cv::Mat Rcl_);
+    cv::Mat GetRcl() { return mRcl.clone(); }
+    void SetType(eType type_) { mType = type_; }
+    void SetRbc(const cv::Mat &Rbc) { mRbc = Rbc.clone(); }  // ctor #1 of the reference leaves mRbc unset
+    // PatchMatch parameters the reference hard-codes at the call site (src/gyro_aided_tracker.cpp:276-277)
+    void SetPatchMatchParams(int iterations, int pyramids) { mIterations = iterations, mPyramids = pyramids; }
+
+    int GyroPredictFeatures();
+    int GyroPredictFeaturesAndOpticalFlowRefined();
+    void IntegrateGyroMeasurements();
+    cv::Mat IntegrateOneGyroMeasurement(cv::Point3f &gyro, double dt);
+    void GyroPredictOnePixel(cv::Point2f &pt_ref, cv::Point2f &pt_predict, cv::Point2f &pt_predict_distort,
+                             cv::Point2f &flow);
+
+public:  // data members keep the reference's names (include/gyro_aided_tracker.h:173-259)
+    double mTimeStamp, mTimeStampRef;
+    const cv::Mat &mImgGrayRef;
+    const cv::Mat &mImgGrayCur;
+    const std::vector<cv::KeyPoint> &mvKeysRef, &mvKeysRefUn, &mvKeysCur, &mvKeysCurUn;
+    const std::vector<IMU::Point> &mvImuFromLastFrame;
+
+    std::vector<cv::Point2f> mvPtPredict, mvPtPredictUn, mvPtGyroPredict, mvPtGyroPredictUn;
+    std::vector<std::vector<cv::Point2f>> mvvPtPredictCorners, mvvPtPredictCornersUn, mvvFlowsPredictCorners;
+    std::vector<cv::uchar> mvStatus;
+    std::vector<float> mvError;
+
+    int mHalfPatchSize;
+    std::vector<cv::Point2f> mvPatchCorners;
+    std::vector<cv::Mat> mvAffineDeformationMatrix;
+
+    std::vector<cv::Point2f> mvPtPredictAfterPatchMatched, mvPtPredictAfterPatchMatchedUn;
+    std::vector<cv::uchar> mvStatusAfterPatchMatched;
+    std::vector<double> mvPixelErrorsOfPatchMatched, mvDistanceBetweenPredictedAndPatchMatched;
+    std::vector<float> mvNccAfterPatchMatched;
+    std::vector<cv::Point2f> mvFlowsPredictUn;
+
+    float mTimeCostGyroPredict = 0, mTimeCostOptFlow = 0, mTimeCostOptFlowResultFilterOut = 0;
+
+    cv::Mat mRbc, mRcl;
+    float mr11, mr12, mr13, mr21, mr22, mr23, mr31, mr32, mr33;
+    cv::Point3f mBias;
+    cv::Mat mK, mKRKinv;
+    float mfx, mfy, mcx, mcy, mfx_inv, mfy_inv;
+    cv::Mat mDistCoef;
+    float mk1, mk2, mp1, mp2, mk3;
+    int mWidth, mHeight, mN;
+    const cv::Mat &mNormalizeTable;
+
+    bool mbHasGyroPredictInitial = true, mbConsiderIllumination = true, mbConsiderAffineDeformation = false,
+         mbRegularizationPenalty = false;
+    eType mType;
+    ePredictMethod mPredictMethod;
+    int mIterations = 10, mPyramids = 3;
+};

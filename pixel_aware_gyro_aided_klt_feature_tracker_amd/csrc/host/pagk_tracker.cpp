@@ -1,0 +1,90 @@
+// pagk_tracker.cpp -- C entry point over the C++ API shell, so that tests (and hosts in other
+// languages) can drive GyroAidedTracker::TrackFeatures() end to end: libpagk_tracker.so.
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "gyro_aided_tracker.h"
+#include "patch_match.h"
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *pagk_tracker_last_error(void) { return g_err.c_str(); }
+
+// One frame pair through the reference's call stack (apps: RealSenseD435i.cpp:244-251):
+// GyroAidedTracker(ctor #1) -> SetRcl(Rcl) or gyro integration -> TrackFeatures().
+//   Rcl: 9 floats row-major, or NULL to integrate `imu` (n_imu x 7: ax ay az wx wy wz t) like the reference.
+// Outputs (n each): final mvStatus, mvPtPredictUn, mvPtPredict, and PatchMatch's raw vectors.
+// Returns the number of tracked features (TrackFeatures' return value) or -100 on an exception.
+int pagk_tracker_track_features(const unsigned char *img_ref, const unsigned char *img_cur, int width, int height,
+                                long step, int n, const float *keys_ref /*n x 2*/, const float *K /*3x3*/,
+                                const float *dist /*4*/, int type, int half_patch, int iterations, int pyramids,
+                                const float *Rcl, const double *imu, int n_imu, double t_ref, double t_cur,
+                                unsigned char *status_out, float *pt_predict_un, float *pt_predict,
+                                unsigned char *status_pm, float *pt_pm_un, double *pix_err, double *dist_pred,
+                                float *affine_out /*n x 4 or NULL*/)
+{
+    try {
+        cv::Mat ref(height, width, cv::CV_8UC1, const_cast<unsigned char *>(img_ref), (size_t)step);
+        cv::Mat cur(height, width, cv::CV_8UC1, const_cast<unsigned char *>(img_cur), (size_t)step);
+        std::vector<cv::KeyPoint> keys(n), none;
+        for (int i = 0; i < n; i++) keys[i].pt = cv::Point2f(keys_ref[2 * i], keys_ref[2 * i + 1]);
+        cv::Mat Km(3, 3, cv::CV_32F), Dm(1, 4, cv::CV_32F), table;
+        for (int k = 0; k < 9; k++) Km.at<float>(k / 3, k % 3) = K[k];
+        for (int k = 0; k < 4; k++) Dm.at<float>(k) = dist[k];
+        std::vector<IMU::Point> vimu;
+        for (int k = 0; k < n_imu; k++)
+            vimu.emplace_back((float)imu[7 * k], (float)imu[7 * k + 1], (float)imu[7 * k + 2], (float)imu[7 * k + 3],
+                              (float)imu[7 * k + 4], (float)imu[7 * k + 5], imu[7 * k + 6]);
+        GyroAidedTracker trk(t_cur, t_ref, ref, cur, keys, none, keys, none, vimu, cv::Point3f(0, 0, 0), Km, Dm, table,
+                             (GyroAidedTracker::eType)type, GyroAidedTracker::PIXEL_AWARE_PREDICTION, "", half_patch);
+        trk.SetPatchMatchParams(iterations, pyramids);
+        int ret;
+        if (Rcl) {
+            cv::Mat R(3, 3, cv::CV_32F);
+            for (int k = 0; k < 9; k++) R.at<float>(k / 3, k % 3) = Rcl[k];
+            // TrackFeatures() starts with IntegrateGyroMeasurements(); with no IMU samples that
+            // leaves Rcl = I, so set the rotation afterwards through the same dispatch by hand.
+            trk.SetRcl(R);
+            if (type == GyroAidedTracker::GYRO_PREDICT)
+                ret = trk.GyroPredictFeatures();
+            else {
+                // flags as TrackFeatures sets them (:384-414)
+                trk.mbHasGyroPredictInitial = type != GyroAidedTracker::IMAGE_ONLY_OPTICAL_FLOW_CONSIDER_ILLUMINATION;
+                trk.mbConsiderIllumination = type != GyroAidedTracker::GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED;
+                trk.mbConsiderAffineDeformation =
+                    type == GyroAidedTracker::IMAGE_ONLY_OPTICAL_FLOW_CONSIDER_ILLUMINATION || type == 4 || type == 6;
+                trk.mbRegularizationPenalty = type == 6;
+                ret = trk.GyroPredictFeaturesAndOpticalFlowRefined();
+            }
+        } else {
+            ret = trk.TrackFeatures();
+        }
+        for (int i = 0; i < n; i++) {
+            status_out[i] = trk.mvStatus[i];
+            pt_predict_un[2 * i] = trk.mvPtPredictUn[i].x, pt_predict_un[2 * i + 1] = trk.mvPtPredictUn[i].y;
+            pt_predict[2 * i] = trk.mvPtPredict[i].x, pt_predict[2 * i + 1] = trk.mvPtPredict[i].y;
+            if ((int)trk.mvStatusAfterPatchMatched.size() == n) {
+                status_pm[i] = trk.mvStatusAfterPatchMatched[i];
+                pt_pm_un[2 * i] = trk.mvPtPredictAfterPatchMatchedUn[i].x;
+                pt_pm_un[2 * i + 1] = trk.mvPtPredictAfterPatchMatchedUn[i].y;
+                pix_err[i] = trk.mvPixelErrorsOfPatchMatched[i];
+                dist_pred[i] = trk.mvDistanceBetweenPredictedAndPatchMatched[i];
+            }
+            if (affine_out) {
+                const cv::Mat &A = trk.mvAffineDeformationMatrix[i];
+                for (int k = 0; k < 4; k++) affine_out[4 * i + k] = A.empty() ? 0.f : A.at<float>(k / 2, k % 2);
+            }
+        }
+        return ret;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -100;
+    }
+}
+
+void pagk_tracker_release(void) { PatchMatch::ReleaseContext(); }
+}

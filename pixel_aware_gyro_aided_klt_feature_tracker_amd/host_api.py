@@ -1,0 +1,58 @@
+"""ctypes access to the C++ API shell (libpagk_tracker.so: the reference's GyroAidedTracker /
+PatchMatch classes over the C ABI).  Used by the tests to drive TrackFeatures() end to end."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+LIB_PATH = os.path.join(capi.PKG_DIR, "libpagk_tracker.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        capi.load()  # libpagk_hip.so first (RTLD_GLOBAL), the shell links against it
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(LIB_PATH)
+        vp, i = C.c_void_p, C.c_int
+        lib.pagk_tracker_track_features.restype = C.c_int
+        lib.pagk_tracker_track_features.argtypes = [vp, vp, i, i, C.c_long, i, vp, vp, vp, i, i, i, i, vp, vp, i,
+                                                    C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.pagk_tracker_last_error.restype = C.c_char_p
+        lib.pagk_tracker_release.restype = None
+        _lib = lib
+    return _lib
+
+
+def track_features(img_ref, img_cur, keys_ref, K, dist, *, type=4, half_patch=5, iterations=10, pyramids=3,
+                   Rcl=None, imu=None, t_ref=0.0, t_cur=0.0):
+    """GyroAidedTracker(ctor #1) -> TrackFeatures() (reference Examples/Demo/RealSenseD435i.cpp:244-251)."""
+    lib = load()
+    n = int(keys_ref.shape[0])
+    nn = max(n, 1)
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    keys_ref = np.ascontiguousarray(keys_ref, np.float32)
+    R = None if Rcl is None else np.ascontiguousarray(Rcl, np.float32)
+    imu_a = None if imu is None else np.ascontiguousarray(imu, np.float64)
+    out = dict(status=np.zeros(nn, np.uint8), pt_predict_un=np.zeros((nn, 2), np.float32),
+               pt_predict=np.zeros((nn, 2), np.float32), status_pm=np.zeros(nn, np.uint8),
+               pt_pm_un=np.zeros((nn, 2), np.float32), pix_err=np.zeros(nn, np.float64),
+               dist_pred=np.zeros(nn, np.float64), affine=np.zeros((nn, 4), np.float32))
+    ret = lib.pagk_tracker_track_features(
+        img_ref.ctypes.data, img_cur.ctypes.data, img_ref.shape[1], img_ref.shape[0], img_ref.strides[0], n,
+        keys_ref.ctypes.data, K.ctypes.data, dist.ctypes.data, type, half_patch, iterations, pyramids,
+        None if R is None else R.ctypes.data, None if imu_a is None else imu_a.ctypes.data,
+        0 if imu_a is None else int(imu_a.shape[0]), t_ref, t_cur,
+        out["status"].ctypes.data, out["pt_predict_un"].ctypes.data, out["pt_predict"].ctypes.data,
+        out["status_pm"].ctypes.data, out["pt_pm_un"].ctypes.data, out["pix_err"].ctypes.data,
+        out["dist_pred"].ctypes.data, out["affine"].ctypes.data)
+    if ret == -100:
+        raise RuntimeError("GyroAidedTracker: " + lib.pagk_tracker_last_error().decode())
+    return ret, {k: v[:n] for k, v in out.items()}

@@ -1,0 +1,89 @@
+"""The C++ API shell (reference class names / signatures over the C ABI)."""
+import numpy as np
+import pytest
+
+from oracle import pagk_oracle as orc
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, host_api, synth
+
+
+def _scene(n=200, seed=0x5EED0700):
+    cam = synth.D435I
+    w = synth.make_workload("host", 320, 240, n, seed=seed, half_patch=5, iterations=10, pyramids=3, camera=cam,
+                            omega=(0.3, -0.4, 1.2), gyro_error=(0.003, -0.002, 0.004), edge_fraction=0.2)
+    R = synth.rodrigues(np.array((0.003, -0.002, 0.004))) @ synth.rodrigues(np.array((0.3, -0.4, 1.2)) * 0.05)
+    K = cam.K.astype(np.float32)
+    return cam, w, R.astype(np.float32), K
+
+
+def _oracle_predict(cam, w, R32, K32, h):
+    # mKRKinv = mK * mRcl * mK.inv()  (reference src/gyro_aided_tracker.cpp:518), CV_32F products
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    Kinv = np.linalg.inv(K32.astype(np.float64)).astype(np.float32)
+    KRK = mul(mul(K32, R32), Kinv)
+    p = capi.make_params(camera=cam)
+    return orc.gyro_predict(p, 320, 240, h, KRK, R32[2, :], w.pt_ref), KRK
+
+
+def test_shell_gyro_predict_matches_oracle(built):
+    # type 1 (GYRO_PREDICT): GyroPredictFeatures only -- pure host code, runs without a GPU
+    cam, w, R32, K32 = _scene()
+    ret, out = host_api.track_features(w.img_ref, w.img_cur, w.pt_ref, K32, cam.dist, type=1, half_patch=5, Rcl=R32)
+    (pu, pd, st, A), _ = _oracle_predict(cam, w, R32, K32, 5)
+    assert ret == int(st.sum()) and 0 < ret < w.n            # the edge set produces some rejects
+    assert np.array_equal(out["status"], st)
+    # mK.inv() is third-party 3x3 arithmetic (parity unpinned): compare to a few ulps, not bitwise
+    assert np.allclose(out["pt_predict_un"], pu, rtol=0, atol=2e-3)
+    assert np.allclose(out["pt_predict"], pd, rtol=0, atol=2e-3)
+    assert np.allclose(out["affine"][st > 0], A[st > 0], rtol=0, atol=1e-4)
+
+
+def test_shell_integrates_gyro_like_the_reference(built):
+    # TrackFeatures() integrates the IMU samples itself (mid-point rule, Rodrigues; :521-587)
+    cam, w, _, K32 = _scene(n=50)
+    wv = np.array((0.3, -0.4, 1.2))
+    t = np.linspace(0.0, 0.05, 11)
+    imu = np.zeros((11, 7))
+    imu[:, 3:6] = wv
+    imu[:, 6] = t
+    ret, out = host_api.track_features(w.img_ref, w.img_cur, w.pt_ref, K32, cam.dist, type=1, half_patch=5, imu=imu,
+                                       t_ref=0.0, t_cur=0.05)
+    R = synth.rodrigues(wv * 0.05).T            # Rcl = Rbc^T dR^T Rbc with Rbc = I
+    H = cam.K @ R @ np.linalg.inv(cam.K)
+    pr = w.pt_ref.astype(np.float64)
+    d = H[2, 0] * pr[:, 0] + H[2, 1] * pr[:, 1] + H[2, 2]
+    want = np.stack([(H[0, 0] * pr[:, 0] + H[0, 1] * pr[:, 1] + H[0, 2]) / d,
+                     (H[1, 0] * pr[:, 0] + H[1, 1] * pr[:, 1] + H[1, 2]) / d], axis=1)
+    ok = out["status"] > 0
+    assert ok.sum() > 30 and np.abs(out["pt_predict_un"][ok] - want[ok]).max() < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_", [2, 3, 4, 5, 6])
+def test_shell_track_features_end_to_end(built, type_):
+    # the whole reference call stack for one frame pair, every eType, against the oracle chain
+    cam, w, R32, K32 = _scene()
+    ret, out = host_api.track_features(w.img_ref, w.img_cur, w.pt_ref, K32, cam.dist, type=type_, half_patch=5,
+                                       iterations=10, pyramids=3, Rcl=R32)
+    flags = {2: (1, 0, 0, 0), 3: (1, 1, 0, 0), 4: (1, 1, 1, 0), 5: (0, 1, 1, 0), 6: (1, 1, 1, 1)}[type_]
+    gyro, ill, aff, pen = (bool(v) for v in flags)
+    if gyro:
+        # feed the oracle the shell's own prediction so that only the path under test differs
+        r1, o1 = host_api.track_features(w.img_ref, w.img_cur, w.pt_ref, K32, cam.dist, type=1, half_patch=5, Rcl=R32)
+        pt_init, A, st_in = o1["pt_predict_un"].copy(), o1["affine"].copy(), o1["status"].copy()
+    else:
+        pt_init, st_in = w.pt_ref.copy(), np.ones(w.n, np.uint8)
+        A = np.tile(np.array([1, 0, 0, 1], np.float32), (w.n, 1))
+    p = capi.make_params(half_patch=5, iterations=10, pyramids=3, has_gyro=gyro, illumination=ill, affine=aff,
+                         penalty=pen, camera=cam)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, pt_init, A, st_in)
+    n = w.n
+    assert np.array_equal(out["status_pm"], ref["status"][:n])
+    assert np.array_equal(out["pt_pm_un"], ref["pt_un"][:n])
+    assert np.array_equal(out["pix_err"], ref["pix_err"][:n]) and np.array_equal(out["dist_pred"], ref["dist_pred"][:n])
+    n_ok, st, pp, ppu = orc.post_filter(5, ref["status"][:n], ref["pix_err"][:n], ref["dist_pred"][:n],
+                                        ref["pt_dist"][:n], ref["pt_un"][:n])
+    assert ret == n_ok and np.array_equal(out["status"], st)
+    keep = st > 0
+    assert np.array_equal(out["pt_predict_un"][keep], ref["pt_un"][:n][keep])
+    host_api.load().pagk_tracker_release()
