@@ -169,50 +169,61 @@ __device__ __forceinline__ double soft_log(double x)
 // Operation order of Eigen 3.3's fixed-size 4x4 path (unblocked LLT that stops at a
 // non-positive pivot and leaves the rest of the matrix untouched, fully unrolled
 // triangular solves, SSE2-shaped squaredNorm).  M: lower triangle is read and overwritten.
-__device__ __forceinline__ void llt4_inplace(double (&M)[4][4])
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        double x = M[k][k];
-        if (k > 0) {
-            double s = M[k][0] * M[k][0];
-#pragma unroll
-            for (int j = 1; j < k; j++) s += M[k][j] * M[k][j];
-            x -= s;
-        }
-        if (x <= 0.0) return;
-        M[k][k] = x = sqrt(x);
-#pragma unroll
-        for (int i = k + 1; i < 4; i++) {
-            if (k > 0) {
-                double s = M[i][0] * M[k][0];
-#pragma unroll
-                for (int j = 1; j < k; j++) s += M[i][j] * M[k][j];
-                M[i][k] -= s;
-            }
-            M[i][k] /= x;
-        }
-    }
-}
-
+// Straight-line form (selects instead of the early return) so that the independent divides of a
+// column, and the forward substitution, can overlap: the f64 divide (~100 cycles) and sqrt (~146)
+// chains are what the solve costs.  `ok_k` = "column k was factorised": the reference returns at the
+// first pivot with x <= 0 (a NaN pivot does NOT stop it: `x <= 0` is false), leaving that column and
+// everything right of it untouched.  Values computed speculatively past a failed pivot are dropped by
+// the selects.
 __device__ __forceinline__ double llt4_solve_norm(double (&M)[4][4], const double (&b)[4], double (&x)[4])
 {
-    llt4_inplace(M);
+    const double H00 = M[0][0], H10 = M[1][0], H11 = M[1][1], H20 = M[2][0], H21 = M[2][1], H22 = M[2][2];
+    const double H30 = M[3][0], H31 = M[3][1], H32 = M[3][2], H33 = M[3][3];
+    // column 0
+    const bool ok0 = !(H00 <= 0.0);
+    const double d0 = ok0 ? sqrt(H00) : H00;
+    const double L10 = ok0 ? H10 / d0 : H10;
+    const double L20 = ok0 ? H20 / d0 : H20;
+    const double L30 = ok0 ? H30 / d0 : H30;
+    // column 1
+    const double x1 = H11 - L10 * L10;
+    const bool ok1 = ok0 && !(x1 <= 0.0);
+    const double d1 = ok1 ? sqrt(x1) : H11;
+    const double L21 = ok1 ? (H21 - L20 * L10) / d1 : H21;
+    const double L31 = ok1 ? (H31 - L30 * L10) / d1 : H31;
+    // column 2
+    double s = L20 * L20;
+    s += L21 * L21;
+    const double x2 = H22 - s;
+    const bool ok2 = ok1 && !(x2 <= 0.0);
+    const double d2 = ok2 ? sqrt(x2) : H22;
+    s = L30 * L20;
+    s += L31 * L21;
+    const double L32 = ok2 ? (H32 - s) / d2 : H32;
+    // column 3
+    s = L30 * L30;
+    s += L31 * L31;
+    s += L32 * L32;
+    const double x3 = H33 - s;
+    const bool ok3 = ok2 && !(x3 <= 0.0);
+    const double d3 = ok3 ? sqrt(x3) : H33;
+    // L y = b   (lower solve: c0 + (c1 + c2) for the 3-term row)
     double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3];
-    r0 /= M[0][0];
-    r1 -= M[1][0] * r0;
-    r1 /= M[1][1];
-    r2 -= M[2][0] * r0 + M[2][1] * r1;
-    r2 /= M[2][2];
-    r3 -= M[3][0] * r0 + (M[3][1] * r1 + M[3][2] * r2);
-    r3 /= M[3][3];
-    r3 /= M[3][3];
-    r2 -= M[3][2] * r3;
-    r2 /= M[2][2];
-    r1 -= M[2][1] * r2 + M[3][1] * r3;
-    r1 /= M[1][1];
-    r0 -= (M[1][0] * r1 + M[2][0] * r2) + M[3][0] * r3;
-    r0 /= M[0][0];
+    r0 /= d0;
+    r1 -= L10 * r0;
+    r1 /= d1;
+    r2 -= L20 * r0 + L21 * r1;
+    r2 /= d2;
+    r3 -= L30 * r0 + (L31 * r1 + L32 * r2);
+    r3 /= d3;
+    // L^T x = y  (upper solve: (c0 + c1) + c2)
+    r3 /= d3;
+    r2 -= L32 * r3;
+    r2 /= d2;
+    r1 -= L21 * r2 + L31 * r3;
+    r1 /= d1;
+    r0 -= (L10 * r1 + L20 * r2) + L30 * r3;
+    r0 /= d0;
     x[0] = r0;
     x[1] = r1;
     x[2] = r2;

@@ -45,6 +45,7 @@ struct pagk_ctx {
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
+    bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
 
@@ -116,6 +117,34 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     level_dims(s.w, s.h, s.L, lw, lh);
     dim3 blk(32, 8);
     if (ctx->ev_pyr[0]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
+    if (s.L <= 4 && !ctx->unfused_pyramid) {
+        PyrArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.src = src0;
+        pa.pitch = pitch0;
+        pa.wrap0 = wrap0;
+        pa.n_levels = s.L;
+        int nb = 0;
+        for (int l = 0; l < 4; l++) {
+            pa.first_block[l] = nb;
+            if (l < s.L) {
+                pa.cols[l] = lw[l];
+                pa.rows[l] = lh[l];
+                pa.u8[l] = s.u8[l];
+                pa.quad[l] = s.quad[l];
+                nb += (lw[l] * lh[l] + 255) / 256;
+            }
+        }
+        pa.first_block[4] = nb;
+        for (int l = s.L; l < 4; l++) pa.first_block[l] = nb;  // empty ranges for absent levels
+        hipLaunchKernelGGL(k_pyramid_fused, dim3(nb), dim3(256), 0, ctx->stream, pa);
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->ev_pyr[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+        ctx->pyr_timed = true;
+        s.wrap0 = wrap0;
+        s.valid = true;
+        return PAGK_OK;
+    }
     const uint8_t *src = src0;
     int64_t pitch = pitch0;
     for (int l = 0; l < s.L; l++) {
@@ -143,7 +172,6 @@ int check_params(const pagk_params *p)
     if (p->half_patch < 1 || p->half_patch > PAGK_MAX_HALF_PATCH) return PAGK_E_ARG;
     if (p->iterations < 0 || p->pyramids < 1 || p->pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
     if (p->inverse) return PAGK_E_UNSUPPORTED;        // src/patch_match.cpp:220 "not support yet"
-    if (p->calculate_ncc) return PAGK_E_UNSUPPORTED;  // PatchMatch::NCC (:433-469): next row, see DESIGN.md
     return PAGK_OK;
 }
 
@@ -413,6 +441,7 @@ int pagk_create(pagk_ctx **out, int device)
         return PAGK_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     for (int k = 0; k < 2; k++) {
         if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
             pagk_destroy(ctx);

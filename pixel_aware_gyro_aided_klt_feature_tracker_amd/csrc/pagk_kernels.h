@@ -55,6 +55,66 @@ __global__ void k_build_quads(const uint8_t *__restrict__ src, int64_t pitch, in
     quad[(int64_t)r * cols + c] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
 }
 
+// One launch for the whole pyramid (levels <= 3): every level-l pixel is re-derived from level 0 by
+// l nested rounded 2x2 means -- exactly the values the level-by-level cv::resize chain produces
+// (:69-70), because each stage rounds to a byte before the next.  Removes the inter-level launch
+// dependencies: 1 launch instead of 2L-1 per frame.  Blocks are level-uniform (blockIdx ranges).
+struct PyrArgs {
+    const uint8_t *src;  // level 0
+    int64_t pitch;
+    int wrap0;
+    int n_levels;
+    int cols[4], rows[4];
+    int first_block[5];  // blocks [first_block[l], first_block[l+1]) belong to level l
+    uint8_t *u8[4];      // u8[0] unused
+    uint32_t *quad[4];
+};
+
+template <int L>
+__device__ __forceinline__ uint32_t pyr_pixel(const uint8_t *__restrict__ src, int64_t pitch, int r, int c)
+{
+    if constexpr (L == 0) {
+        return src[(int64_t)r * pitch + c];
+    } else {
+        return (pyr_pixel<L - 1>(src, pitch, 2 * r, 2 * c) + pyr_pixel<L - 1>(src, pitch, 2 * r, 2 * c + 1) +
+                pyr_pixel<L - 1>(src, pitch, 2 * r + 1, 2 * c) + pyr_pixel<L - 1>(src, pitch, 2 * r + 1, 2 * c + 1) + 2) >> 2;
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void pyr_emit(const PyrArgs &a, int idx)
+{
+    const int cols = a.cols[L], rows = a.rows[L];
+    if (idx >= cols * rows) return;
+    const int r = idx / cols, c = idx - r * cols;
+    const int wrap = L == 0 ? a.wrap0 : 1;
+    auto px = [&](int rr, int cc) -> uint32_t {
+        if (cc >= cols) {
+            if (!wrap) return 0u;
+            cc -= cols;
+            rr += 1;
+        }
+        return rr < rows ? pyr_pixel<L>(a.src, a.pitch, rr, cc) : 0u;
+    };
+    const uint32_t d0 = px(r, c), d1 = px(r, c + 1), d2 = px(r + 1, c), d3 = px(r + 1, c + 1);
+    a.quad[L][idx] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+    if constexpr (L > 0) a.u8[L][idx] = (uint8_t)d0;
+}
+
+__global__ void __launch_bounds__(256) k_pyramid_fused(PyrArgs a)
+{
+    const int b = blockIdx.x;
+    if (b < a.first_block[1]) {
+        pyr_emit<0>(a, (b - a.first_block[0]) * 256 + threadIdx.x);
+    } else if (b < a.first_block[2]) {
+        pyr_emit<1>(a, (b - a.first_block[1]) * 256 + threadIdx.x);
+    } else if (b < a.first_block[3]) {
+        pyr_emit<2>(a, (b - a.first_block[2]) * 256 + threadIdx.x);
+    } else {
+        pyr_emit<3>(a, (b - a.first_block[3]) * 256 + threadIdx.x);
+    }
+}
+
 // ---- shared epilogue: SetMatcher + DistortPoints for one feature --------------------------------
 __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
                                               float lastCost, int level0_ran, float ncc, int iters)
@@ -76,6 +136,38 @@ __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p
     }
     if (a.ncc) a.ncc[i] = ncc;  // :365 / :95
     if (a.iters) a.iters[i] = iters;
+}
+
+// PatchMatch::NCC, src/patch_match.cpp:433-469, one thread.  Always on the level-0 images (:358,:361);
+// loop order x outer, y inner (:438-439); float sums; the final division promotes to double (:468).
+__device__ inline float ncc_serial(const TrackArgs &a, float rx, float ry, float cx, float cy, float A00, float A01,
+                                   float A10, float A11)
+{
+    const int h = a.half;
+    const float Pf = (float)((2 * h + 1) * (2 * h + 1));
+    const DevLevel &R = a.l1[0], &C = a.l2[0];
+    auto cur_at = [&](int x, int y) {
+        if (!a.use_affine) return sample<true>(C, cx + x, cy + y);  // warp_mat.empty() (:446-447)
+        float wx = A00 * x + A01 * y, wy = A10 * x + A11 * y;       // :449-450
+        return sample<true>(C, cx + wx, cy + wy);
+    };
+    float mean_ref = 0.0f, mean_cur = 0.0f;
+    for (int x = -h; x <= h; x++)
+        for (int y = -h; y <= h; y++) {
+            mean_ref += sample<true>(R, rx + x, ry + y);
+            mean_cur += cur_at(x, y);
+        }
+    mean_ref /= Pf;  // :457  float / size_t
+    mean_cur /= Pf;
+    float num = 0, d1 = 0, d2 = 0;
+    for (int x = -h; x <= h; x++)
+        for (int y = -h; y <= h; y++) {
+            float vr = sample<true>(R, rx + x, ry + y), vc = cur_at(x, y);
+            num += ((vr - mean_ref) * (vc - mean_cur));
+            d1 += (vr - mean_ref) * (vr - mean_ref);
+            d2 += (vc - mean_cur) * (vc - mean_cur);
+        }
+    return (float)((double)num / sqrt((double)(d1 * d2) + 1e-10));
 }
 
 // ---- one thread per feature: the reference's loop nest, verbatim in shape -----------------------
@@ -161,7 +253,9 @@ __global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
         p2x = ptx + dx;  // :348
         p2y = pty + dy;
     }
-    write_outputs(a, i, p2x, p2y, succ, lastCost, 1, 1.0f, iters);
+    float ncc = 1.0f;  // :365
+    if (a.calc_ncc) ncc = ncc_serial(a, a.pt_ref[2 * i], a.pt_ref[2 * i + 1], p2x, p2y, A00, A01, A10, A11);
+    write_outputs(a, i, p2x, p2y, succ, lastCost, 1, ncc, iters);
 }
 
 // ---- one workgroup per feature -----------------------------------------------------------------
@@ -231,6 +325,7 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         int p = tid + kBlock * r;
+        p = p < P ? p : P - 1;  // lanes past the patch shadow the last pixel (never stored)
         int yy = p / Wd, xx = p - yy * Wd;
         int x = xx - h, y = yy - h;
         px[r] = (float)x;
@@ -328,12 +423,19 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
             // lies in [0, cols-1) x [0, rows-1) => clamps are no-ops and can be skipped.
             const bool interior = (bx - ext_x >= 0.0f) && (bx + ext_x < L2.fcols_m1) &&
                                   (by - ext_y >= 0.0f) && (by + ext_y < L2.frows_m1);
+            // all rounds' gathers are issued before any is consumed (lanes past the patch sample
+            // a valid pixel and simply do not store)
+            Five smp[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float X = bx + wx[r], Y = by + wy[r];
+                smp[r] = interior ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
+            }
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 int p = tid + kBlock * r;
                 if (p < P) {
-                    float X = bx + wx[r], Y = by + wy[r];
-                    Five s = interior ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
+                    const Five &s = smp[r];
                     float e = s.c + db - gain * s1[r];   // :252-253
                     float Ix = 0.5f * (s.xp - s.xm);     // :259-260
                     float Iy = 0.5f * (s.yp - s.ym);     // :261-262
@@ -413,7 +515,64 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
         // the next level's first sampling pass overwrites the streams: every lane left the loop
         // after the same barrier, and cslot is rewritten before the next pass's first barrier.
     }
-    if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, 1.0f, iters);
+    float ncc = 1.0f;  // :365
+    if (a.calc_ncc) {
+        // PatchMatch::NCC (:433-469) on the level-0 images at the final point.  Same structure as an
+        // iteration: every lane samples its pixels, the f32 sums run in the reference's order (x
+        // outer, y inner: sample k of the NCC order is patch pixel (x, y) = (k / Wd - h, k % Wd - h))
+        // as DPP row chains.  Five f32 arrays of PP floats reuse the stream region.
+        float *vref = reinterpret_cast<float *>(stream), *vcur = vref + PP;
+        float *tnum = vcur + PP, *td1 = tnum + PP, *td2 = td1 + PP;
+        const DevLevel &R0 = a.l1[0], &C0 = a.l2[0];
+        float vr[NR], vc[NR];
+        __syncthreads();  // the last iteration's readers of the streams are done
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int k = tid + kBlock * r;
+            k = k < P ? k : P - 1;
+            int xi = k / Wd - h, yi = k - (k / Wd) * Wd - h;  // x outer, y inner
+            vr[r] = sample<true>(R0, refx + xi, refy + yi);   // :440
+            if (a.use_affine) {
+                float wxx = A00 * xi + A01 * yi, wyy = A10 * xi + A11 * yi;  // :449-450
+                vc[r] = sample<true>(C0, p2x + wxx, p2y + wyy);
+            } else {
+                vc[r] = sample<true>(C0, p2x + xi, p2y + yi);  // :447
+            }
+            if (tid + kBlock * r < P) {
+                vref[tid + kBlock * r] = vr[r];
+                vcur[tid + kBlock * r] = vc[r];
+            }
+        }
+        __syncthreads();
+        const int row = lane >> 4;
+        float *sh_f = reinterpret_cast<float *>(acc);  // 8 floats of scratch
+        if (wave == 0) {  // rows 0/1: mean_ref, mean_cur (:441, :453); rows 2/3 shadow row 0
+            float m = chain_rows_f32<TAIL>(lds_off(row == 1 ? vcur : vref) + 8u * lr, 128u, nfull);
+            if (lr == 0 && row < 2) sh_f[row] = m;
+        }
+        __syncthreads();
+        const float mean_ref = sh_f[0] / (float)P, mean_cur = sh_f[1] / (float)P;  // :457-458
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int k = tid + kBlock * r;
+            if (k < P) {
+                float dr = vr[r] - mean_ref, dc = vc[r] - mean_cur;
+                tnum[k] = dr * dc;  // :463
+                td1[k] = dr * dr;   // :464
+                td2[k] = dc * dc;   // :465
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *src = row == 0 ? tnum : (row == 1 ? td1 : td2);
+            float v = chain_rows_f32<TAIL>(lds_off(src) + 8u * lr, 128u, nfull);
+            if (lr == 0 && row < 3) sh_f[2 + row] = v;
+        }
+        __syncthreads();
+        // numerator / std::sqrt(d1 * d2 + 1e-10): float product, double sum / sqrt / divide (:468)
+        ncc = (float)((double)sh_f[2] / sqrt((double)(sh_f[3] * sh_f[4]) + 1e-10));
+    }
+    if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, ncc, iters);
 #ifdef PAGK_STAMPS
     if (tid == 0 && a.dbg) {
         st[5] = __builtin_amdgcn_s_memtime() - t_begin;

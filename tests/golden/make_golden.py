@@ -47,6 +47,9 @@ case("identity_init_penalty", synth.make_workload("g", 160, 120, 64, seed=0x601D
                                                   pyramids=3, motion="translation", has_gyro=False), penalty=True)
 # features hugging the border (clamped taps, linear-address wrap at the right/bottom edge)
 case("edge_features", base(0x601D0106, edge_fraction=1.0))
+# PatchMatch::NCC on (bCalculateNCC_), with and without the affine warp (:356-363)
+case("ncc_affine", base(0x601D010A), ncc=True)
+case("ncc_noaffine_h10", base(0x601D010B, half_patch=10, iterations=30), ncc=True, affine=False)
 # some features switched off by the producer (status_in = 0)
 w = base(0x601D0107)
 w.status_in[::3] = 0
@@ -68,7 +71,7 @@ def main():
         p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids,
                              has_gyro=w.has_gyro, camera=w.camera,
                              illumination=flags.get("illumination", True), affine=flags.get("affine", True),
-                             penalty=flags.get("penalty", False))
+                             penalty=flags.get("penalty", False), ncc=flags.get("ncc", False))
         out = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=1)
         cam = np.array([w.camera.fx, w.camera.fy, w.camera.cx, w.camera.cy, *w.camera.dist[:4]], np.float64)
         np.savez_compressed(
@@ -76,7 +79,8 @@ def main():
             img_ref=w.img_ref, img_cur=w.img_cur, pt_ref=w.pt_ref, pt_init=w.pt_init, affine=w.affine,
             status_in=w.status_in, camera=cam,
             cfg=np.array([w.half_patch, w.iterations, w.pyramids, int(w.has_gyro), int(flags.get("illumination", True)),
-                          int(flags.get("affine", True)), int(flags.get("penalty", False))], np.int32),
+                          int(flags.get("affine", True)), int(flags.get("penalty", False)), int(flags.get("ncc", False))],
+                         np.int32),
             **{"out_" + k: v[:w.n] for k, v in out.items()})
         print(f"{name}: n={w.n} ok={int(out['status'][:w.n].sum())} mean iters {out['iters'][:w.n].mean():.2f}")
 

@@ -24,7 +24,8 @@ def load_golden(name):
     cam = z["camera"]
     camera = synth.Camera(float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), tuple(float(v) for v in cam[4:8]))
     params = capi.make_params(half_patch=int(cfg[0]), iterations=int(cfg[1]), pyramids=int(cfg[2]), has_gyro=bool(cfg[3]),
-                              illumination=bool(cfg[4]), affine=bool(cfg[5]), penalty=bool(cfg[6]), camera=camera)
+                              illumination=bool(cfg[4]), affine=bool(cfg[5]), penalty=bool(cfg[6]),
+                              ncc=bool(cfg[7]) if len(cfg) > 7 else False, camera=camera)
     inputs = dict(img_ref=z["img_ref"], img_cur=z["img_cur"], pt_ref=z["pt_ref"], pt_init=z["pt_init"],
                   affine=z["affine"], status_in=z["status_in"])
     expected = {k[4:]: z[k] for k in z.files if k.startswith("out_")}

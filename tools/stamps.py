@@ -13,7 +13,7 @@ if not os.path.exists(lib_path):
     subprocess.run(["/opt/rocm/bin/hipcc", *g.HIPCC_FLAGS, "-DPAGK_STAMPS", "-o", lib_path,
                     os.path.join(g.CSRC, "pagk_hip.hip")], check=True)
 capi.LIB_PATH = lib_path
-w = synth.config(1)
+w = synth.config(1, n=int(os.environ.get("PAGK_N", "1000")))
 n = w.n
 dbg = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
 os.environ["PAGK_DBG_PTR"] = str(dbg.data_ptr())
