@@ -92,12 +92,14 @@ def main() -> int:
               file=sys.stderr)
         return 3
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("PAGK_FORCE_DIST") == "1" and "RANK" in os.environ  # exercise RCCL with 1 rank
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, runtime, synth
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
+    distributed.FORCE_COLLECTIVE = force_dist
 
     # identical inputs on every rank (seeded generator), n_total = world x features_per_gpu
     n_total = args.features_per_gpu * world
@@ -134,16 +136,17 @@ def main() -> int:
     # dominant kernel (k_track_block): average launch duration, HIP events recorded by the
     # library on the stream the kernel runs on (pagk_last_kernel_ms); untimed extra launches.
     trk, pyr = [], []
+    torch.cuda.synchronize()
     for _ in range(min(50, max(10, args.steps))):
-        rt.rebuild_current_pyramid()
-        rt.track_shard()
+        rt.rebuild_current_pyramid(1)
+        rt.track_shard(1)
         a, b = rt.ctx.last_kernel_ms()
         trk.append(a)
         pyr.append(b)
     kernel_ms = float(np.mean(trk))
     pyramid_ms = float(np.mean(pyr))
 
-    res = {k: v.cpu().numpy() for k, v in out.items()}  # full length on every rank (gathered when world > 1)
+    res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
@@ -163,7 +166,8 @@ def main() -> int:
                                    "(synthetic stand-in for BASELINE configs[1])",
                        "features_total": n_total, "features_active": n_active_total,
                        "sharding": f"contiguous feature blocks x{world} + all-gather" if world > 1 else "none",
-                       "step": "pyramid(current frame) + PatchMatch(all features)" + (" + all-gather" if world > 1 else "")},
+                       "step": "pyramid(current frame; built on a side stream while the previous pair tracks) + "
+                               "PatchMatch(all features)" + (" + all-gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": (f"profiles/{traffic_tag}/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB "
@@ -211,7 +215,7 @@ def main() -> int:
         print(json.dumps(line), flush=True)
 
     rt.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

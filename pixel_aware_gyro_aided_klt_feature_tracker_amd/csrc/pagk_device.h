@@ -98,7 +98,7 @@ __device__ __forceinline__ float sample(const DevLevel &L, float x, float y)
 {
     Coord cx = prep_coord<CLAMP>(x, L.fcols, L.fcols_m1);
     Coord cy = prep_coord<CLAMP>(y, L.frows, L.frows_m1);
-    return bilerp(L.quad[cy.i * L.cols + cx.i], cx, cy);
+    return bilerp(L.quad[(uint32_t)(cy.i * L.cols + cx.i)], cx, cy);
 }
 
 // The five img2 samples one pixel of the GN loop needs (src/patch_match.cpp:252,259-262):
@@ -118,11 +118,12 @@ __device__ __forceinline__ Five sample5(const DevLevel &L, float X, float Y)
     Coord cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
     const uint32_t *q = L.quad;
     int rc = cy.i * L.cols, rp = cyp.i * L.cols, rm = cym.i * L.cols;
-    uint32_t q0 = q[rc + cx.i];
-    uint32_t q1 = q[rc + cxp.i];
-    uint32_t q2 = q[rc + cxm.i];
-    uint32_t q3 = q[rp + cx.i];
-    uint32_t q4 = q[rm + cx.i];
+    // unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
+    uint32_t q0 = q[(uint32_t)(rc + cx.i)];
+    uint32_t q1 = q[(uint32_t)(rc + cxp.i)];
+    uint32_t q2 = q[(uint32_t)(rc + cxm.i)];
+    uint32_t q3 = q[(uint32_t)(rp + cx.i)];
+    uint32_t q4 = q[(uint32_t)(rm + cx.i)];
     Five r;
     r.c = bilerp(q0, cx, cy);
     r.xp = bilerp(q1, cxp, cy);
@@ -179,43 +180,61 @@ __device__ __forceinline__ double llt4_solve_norm(double (&M)[4][4], const doubl
 {
     const double H00 = M[0][0], H10 = M[1][0], H11 = M[1][1], H20 = M[2][0], H21 = M[2][1], H22 = M[2][2];
     const double H30 = M[3][0], H31 = M[3][1], H32 = M[3][2], H33 = M[3][3];
+    // `keep(v)`: an empty asm that pins a value in a VGPR, so the speculative sqrt / divides are
+    // evaluated unconditionally (the compiler otherwise turns `ok ? a / d : h` back into a branch,
+    // which splits the block and serialises the independent ~100-cycle divide chains).
+#define PAGK_KEEP(v) asm volatile("" : "+v"(v))
     // column 0
     const bool ok0 = !(H00 <= 0.0);
-    const double d0 = ok0 ? sqrt(H00) : H00;
-    const double L10 = ok0 ? H10 / d0 : H10;
-    const double L20 = ok0 ? H20 / d0 : H20;
-    const double L30 = ok0 ? H30 / d0 : H30;
+    double sq0 = sqrt(H00);
+    PAGK_KEEP(sq0);
+    const double d0 = ok0 ? sq0 : H00;
+    double q10 = H10 / d0, q20 = H20 / d0, q30 = H30 / d0, r0 = b[0] / d0;
+    PAGK_KEEP(q10);
+    PAGK_KEEP(q20);
+    PAGK_KEEP(q30);
+    const double L10 = ok0 ? q10 : H10;
+    const double L20 = ok0 ? q20 : H20;
+    const double L30 = ok0 ? q30 : H30;
     // column 1
     const double x1 = H11 - L10 * L10;
     const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double d1 = ok1 ? sqrt(x1) : H11;
-    const double L21 = ok1 ? (H21 - L20 * L10) / d1 : H21;
-    const double L31 = ok1 ? (H31 - L30 * L10) / d1 : H31;
+    double sq1 = sqrt(x1);
+    PAGK_KEEP(sq1);
+    const double d1 = ok1 ? sq1 : H11;
+    double q21 = (H21 - L20 * L10) / d1, q31 = (H31 - L30 * L10) / d1;
+    double r1 = (b[1] - L10 * r0) / d1;
+    PAGK_KEEP(q21);
+    PAGK_KEEP(q31);
+    const double L21 = ok1 ? q21 : H21;
+    const double L31 = ok1 ? q31 : H31;
     // column 2
     double s = L20 * L20;
     s += L21 * L21;
     const double x2 = H22 - s;
     const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double d2 = ok2 ? sqrt(x2) : H22;
+    double sq2 = sqrt(x2);
+    PAGK_KEEP(sq2);
+    const double d2 = ok2 ? sq2 : H22;
     s = L30 * L20;
     s += L31 * L21;
-    const double L32 = ok2 ? (H32 - s) / d2 : H32;
+    double q32 = (H32 - s) / d2;
+    double r2 = (b[2] - (L20 * r0 + L21 * r1)) / d2;
+    PAGK_KEEP(q32);
+    const double L32 = ok2 ? q32 : H32;
     // column 3
     s = L30 * L30;
     s += L31 * L31;
     s += L32 * L32;
     const double x3 = H33 - s;
     const bool ok3 = ok2 && !(x3 <= 0.0);
-    const double d3 = ok3 ? sqrt(x3) : H33;
-    // L y = b   (lower solve: c0 + (c1 + c2) for the 3-term row)
-    double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3];
-    r0 /= d0;
-    r1 -= L10 * r0;
-    r1 /= d1;
-    r2 -= L20 * r0 + L21 * r1;
-    r2 /= d2;
-    r3 -= L30 * r0 + (L31 * r1 + L32 * r2);
-    r3 /= d3;
+    double sq3 = sqrt(x3);
+    PAGK_KEEP(sq3);
+    const double d3 = ok3 ? sq3 : H33;
+#undef PAGK_KEEP
+    // L y = b   (lower solve, interleaved above: r_i = (b_i - sum) / d_i with c0 + (c1 + c2) for the
+    // 3-term row) -- only r3 is left
+    double r3 = (b[3] - (L30 * r0 + (L31 * r1 + L32 * r2))) / d3;
     // L^T x = y  (upper solve: (c0 + c1) + c2)
     r3 /= d3;
     r2 -= L32 * r3;

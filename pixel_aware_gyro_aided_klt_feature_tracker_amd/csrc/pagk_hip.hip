@@ -16,7 +16,8 @@ using namespace pagk;
 
 namespace {
 
-constexpr int kSlots = 4;
+constexpr int kSlots = 6;        // 0..3 for the caller, 4/5 = scratch pair of the host-buffer path
+constexpr int kUserSlots = 4;
 
 struct FrameSlot {
     int w = 0, h = 0, L = 0;
@@ -509,7 +510,15 @@ int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms)
     return PAGK_OK;
 }
 
+static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids);
+
 int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
+{
+    if (!ctx || slot < 0 || slot >= kUserSlots) return PAGK_E_ARG;
+    return frame_upload_any(ctx, slot, img, pyramids);
+}
+
+static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
 {
     if (!ctx || slot < 0 || slot >= kSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
     int rc = check_image(img);
@@ -525,7 +534,7 @@ int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_
 int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width, int32_t height,
                           int64_t step, int32_t pyramids)
 {
-    if (!ctx || slot < 0 || slot >= kSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
+    if (!ctx || slot < 0 || slot >= kUserSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
     if (!d_data || width < 1 || height < 1 || step < width) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     FrameSlot &s = ctx->slots[slot];
@@ -539,7 +548,7 @@ int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32
 int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst, int32_t *width,
                               int32_t *height)
 {
-    if (!ctx || slot < 0 || slot >= kSlots || !dst) return PAGK_E_ARG;
+    if (!ctx || slot < 0 || slot >= kUserSlots || !dst) return PAGK_E_ARG;
     FrameSlot &s = ctx->slots[slot];
     if (!s.valid || level < 1 || level >= s.L) return PAGK_E_ARG;  // level 0 is the caller's own image
     int lw[kMaxLevels], lh[kMaxLevels];
@@ -558,7 +567,7 @@ int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref
     if (!ctx) return PAGK_E_ARG;
     int rc = check_params(params);
     if (rc) return rc;
-    if (slot_ref < 0 || slot_ref >= kSlots || slot_cur < 0 || slot_cur >= kSlots) return PAGK_E_ARG;
+    if (slot_ref < 0 || slot_ref >= kUserSlots || slot_cur < 0 || slot_cur >= kUserSlots) return PAGK_E_ARG;
     FrameSlot &sr = ctx->slots[slot_ref], &sc = ctx->slots[slot_cur];
     if (!sr.valid || !sc.valid || sr.L < params->pyramids || sc.L < params->pyramids) return PAGK_E_ARG;
     if (sr.w != sc.w || sr.h != sc.h) return PAGK_E_ARG;
@@ -579,11 +588,10 @@ int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref, 
     if (rc) return rc;
     if ((rc = check_image(ref)) || (rc = check_image(cur))) return rc;
     if (ref->width != cur->width || ref->height != cur->height) return PAGK_E_ARG;
-    // slots 2/3 are the scratch pair of the host-buffer path
-    if ((rc = pagk_frame_upload(ctx, 2, ref, params->pyramids))) return rc;
-    if ((rc = pagk_frame_upload(ctx, 3, cur, params->pyramids))) return rc;
-    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[2],
-                             ctx->slots[3]);
+    if ((rc = frame_upload_any(ctx, 4, ref, params->pyramids))) return rc;
+    if ((rc = frame_upload_any(ctx, 5, cur, params->pyramids))) return rc;
+    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[4],
+                             ctx->slots[5]);
 }
 
 int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, const pagk_image *ref_levels,
@@ -597,7 +605,7 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // caller-built pyramids: every level is uploaded and packed as is; level sizes must be
     // the ones CreatePyramids would produce (int(cols*0.5)), but parents may be odd.
-    FrameSlot *sl[2] = {&ctx->slots[2], &ctx->slots[3]};
+    FrameSlot *sl[2] = {&ctx->slots[4], &ctx->slots[5]};
     const pagk_image *lv[2] = {ref_levels, cur_levels};
     for (int k = 0; k < 2; k++) {
         for (int l = 0; l < n_levels; l++)
@@ -645,8 +653,8 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
         HIPCHK(ctx, hipGetLastError());
         s.valid = true;
     }
-    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[2],
-                             ctx->slots[3]);
+    return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[4],
+                             ctx->slots[5]);
 }
 
 // GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined, Step 3,

@@ -19,6 +19,7 @@ import torch.distributed as dist
 FIELDS = (("pt_un", torch.float32, 2), ("pt_dist", torch.float32, 2), ("status", torch.uint8, 1),
           ("pix_err", torch.float64, 1), ("dist_pred", torch.float64, 1), ("ncc", torch.float32, 1),
           ("iters", torch.int32, 1))
+FORCE_COLLECTIVE = False  # tests: run the all-gather even with one rank
 BYTES_PER_FEATURE = sum(torch.empty(0, dtype=dt).element_size() * k for _, dt, k in FIELDS)  # 41
 
 
@@ -60,22 +61,41 @@ def views_of(buf: torch.Tensor, m: int) -> dict:
     return out
 
 
-def all_gather_results(local: dict, n: int, group=None) -> dict:
-    """One all-gather of every rank's packed slice; returns full-length (n) tensors on every
-    rank, in feature-index order."""
+class Gathered:
+    """The all-gathered packed slices of every rank, left packed on the device: nothing but the
+    collective itself runs per step.  unpack() builds the full-length per-field tensors (feature-index
+    order) when the host actually reads them."""
+
+    def __init__(self, raw: torch.Tensor, world: int, m: int, n: int, slice_bytes: int):
+        self.raw, self.world, self.m, self.n, self.slice_bytes = raw, world, m, n, slice_bytes
+
+    def unpack(self) -> dict:
+        parts = [views_of(self.raw[r * self.slice_bytes:(r + 1) * self.slice_bytes], self.m) for r in range(self.world)]
+        return {name: torch.cat([p[name] for p in parts], dim=0)[:self.n] for name, _, _ in FIELDS}
+
+    # dict-like access so that callers can treat it as the unpacked result
+    def items(self):
+        return self.unpack().items()
+
+    def __getitem__(self, key):
+        return self.unpack()[key]
+
+
+def all_gather_results(local: dict, n: int, group=None, out: torch.Tensor | None = None):
+    """One all-gather of every rank's packed slice (RCCL `ncclAllGather` of bytes under backend
+    "nccl").  Returns the local views when there is a single rank, else a Gathered."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     m = local["_m"]
-    if world == 1:
+    if world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVE):
         return {name: local[name][:n] for name, _, _ in FIELDS}
     buf = local["_buf"]
-    gathered = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
-    dist.all_gather_into_tensor(gathered, buf, group=group)
-    parts = [views_of(gathered[r * buf.numel():(r + 1) * buf.numel()], m) for r in range(world)]
-    full = {}
-    for name, _, _ in FIELDS:
-        full[name] = torch.cat([p[name] for p in parts], dim=0)[:n]
-    return full
+    if out is None or out.numel() != world * buf.numel():
+        out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return Gathered(out, world, m, n, buf.numel())
 
 
-def to_numpy(full: dict) -> dict:
+def to_numpy(full) -> dict:
+    if isinstance(full, Gathered):
+        full = full.unpack()
     return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in full.items()}
