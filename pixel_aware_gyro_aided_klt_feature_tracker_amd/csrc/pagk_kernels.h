@@ -272,8 +272,19 @@ __global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
 //   4. update    -- every lane applies the same update and takes the same exit (:322-343).
 // Dynamic LDS: double stream[8][PP]; float esq[PP]; double cslot[2]; double acc[16];
 //              double upd[5]; float cost[2]      with PP = 32 * ceil(P / 32).
-constexpr int kBlock = 256;
-constexpr int kStreams = 8;
+//
+// MFMA variant (template MFMA = true, 2 waves): for launches with more features than the chip can
+// hold at once, throughput matters more than one workgroup's latency.  v_mfma_f64_4x4x4f64 computes, in
+// each of its 4 blocks, D = C + sum_k A[:,k] B[k,:] as a SEQUENTIAL chain of FMAs in ascending k
+// (measured bit-for-bit on 128000 outputs, tools/microbench7.hip; lane layout: A(q,i,k) in lane
+// 16k+4q+i, B(q,k,j) in lane 16k+4q+j, D(q,i,j) in lane 16i+4q+j).  With k = four consecutive patch
+// pixels, block 0 fed with A = B = J and block 1 with A = -J, B = (e,0,0,0), one instruction advances all
+// sixteen H entries and the four b entries by four pixels in the reference's order -- on the matrix
+// pipe, beside the VALU.  A dependent MFMA takes 52 cycles (13 per pixel vs 5.9 for the DPP rows), so
+// this form loses on latency and wins on issue slots: one wave instead of three, no product streams.
+// Half-size workgroups double the number resident per CU.
+constexpr int kBlock = 256;   // DPP variant
+constexpr int kStreams = 8;   // DPP variant: XX YX YY XE YE X Y E;  MFMA variant: X Y E
 
 __host__ __device__ inline int track_block_pp(int half)
 {
@@ -285,15 +296,27 @@ __host__ __device__ inline size_t track_block_lds_bytes(int half)
     size_t PP = (size_t)track_block_pp(half);
     return kStreams * PP * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;
 }
+// MFMA variant: three f64 streams of PP + 8 (the +8 staggers the banks of neighbouring arrays),
+// X = Ix, Y = Iy, NE = -e, written per iteration, followed by a 16-double constant area
+// (4 x c, 4 x 1.0, 4 x 0.0, pad) that the constant operand lanes re-read with stride 0.
+__host__ __device__ inline size_t track_mfma_lds_bytes(int half)
+{
+    size_t PP = (size_t)track_block_pp(half);
+    return (3 * (PP + 8) + 16) * 8 + PP * 4 + 2 * 8 + 24 * 8 + 5 * 8 + 2 * 4 + 8;
+}
 
 __device__ __forceinline__ uint32_t lds_off(const void *p)
 {
     return (uint32_t)(uintptr_t)p;  // low half of a flat LDS address = offset in the LDS aperture
 }
 
-template <int NR, int TAIL>
-__global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false>
+__global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackArgs a)
 {
+    static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
+    constexpr int kBlock = WAVES * 64;
+    constexpr int kStreams = MFMA ? 3 : 8;
+    constexpr int kAcc = MFMA ? 24 : 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int i = blockIdx.x;
     const int tid = threadIdx.x;
@@ -301,11 +324,13 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
     const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
     const int nfull = P / 32;  // P mod 32 == TAIL
 
+    const int PS = MFMA ? PP + 8 : PP;  // array stride in doubles
     double *stream = reinterpret_cast<double *>(lds_raw);
-    float *esq = reinterpret_cast<float *>(stream + (size_t)kStreams * PP);
+    double *cst = stream + (size_t)kStreams * PS;  // MFMA variant: constant area (16 doubles)
+    float *esq = reinterpret_cast<float *>(cst + (MFMA ? 16 : 0));
     double *cslot = reinterpret_cast<double *>(esq + PP);
     double *acc = cslot + 2;
-    double *sh_upd = acc + 16;
+    double *sh_upd = acc + kAcc;
     float *sh_cost = reinterpret_cast<float *>(sh_upd + 5);
 
     const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
@@ -350,15 +375,34 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
     // stream:       XX   YX   YY   XE   YE   X    Y    X    Y    E    E    cslot
     const int stream_of[12] = {0, 1, 2, 3, 4, 5, 6, 5, 6, 7, 7, 0};
     uint32_t row_addr, row_inc;
-    if (cid < 11) {
+    if (MFMA || cid >= 12) {
+        row_addr = lds_off(esq) + 8u * lr;  // cost rows (MFMA variant: wave 1, all four rows)
+        row_inc = 128u;
+    } else if (cid < 11) {
         row_addr = lds_off(stream + (size_t)stream_of[cid] * PP) + 16u * lr;
         row_inc = 256u;
-    } else if (cid == 11) {
+    } else {
         row_addr = lds_off(cslot);  // every lane re-reads (c, c)
         row_inc = 0u;
-    } else {
-        row_addr = lds_off(esq) + 8u * lr;
-        row_inc = 128u;
+    }
+    // MFMA variant, operand roles of this lane: k = pixel within the group of four, q = block, i = row
+    // (A) or column (B).  q = 0: A = B = J[i];  q = 1: A = J[i], B = (i == 0 ? -e : 0), i.e. b += J * (-e),
+    // the same exact product as the reference's (-J) * e (:293);  q >= 2: zero.  Every operand is a plain
+    // LDS read: streams X Y NE advance by 4 doubles per MFMA, the constants c / 1 / 0 sit in cst[] and are
+    // re-read in place (per-lane step 0).
+    const int mk = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
+    // J[i]: i = 0 -> X, 1 -> Y, 2 -> c, 3 -> 1
+    const double *j_src = mi < 2 ? stream + (size_t)mi * PS + mk : cst + (mi == 2 ? 0 : 4) + mk;
+    const int j_step = mi < 2 ? 4 : 0;
+    const double *a_src = mq < 2 ? j_src : cst + 8 + mk;
+    const int a_step = mq < 2 ? j_step : 0;
+    const double *b_src = mq == 0 ? j_src : ((mq == 1 && mi == 0) ? stream + (size_t)2 * PS + mk : cst + 8 + mk);
+    const int b_step = mq == 0 ? j_step : ((mq == 1 && mi == 0) ? 4 : 0);
+    if constexpr (MFMA) {
+        if (tid < 4) {
+            cst[4 + tid] = 1.0;
+            cst[8 + tid] = 0.0;
+        }
     }
 
     int succ = 1, iters = 0;
@@ -412,6 +456,9 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
             cslot[0] = cd;
             cslot[1] = cd;
         }
+        if constexpr (MFMA) {
+            if (tid < 4) cst[tid] = cd;  // first read after the sampling barrier
+        }
 
         STAMP(0)
         for (int iter = 0; iter < a.iterations; iter++) {  // :215
@@ -440,21 +487,79 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
                     float Ix = 0.5f * (s.xp - s.xm);     // :259-260
                     float Iy = 0.5f * (s.yp - s.ym);     // :261-262
                     double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
-                    stream[0 * PP + p] = dIx * dIx;
-                    stream[1 * PP + p] = dIy * dIx;
-                    stream[2 * PP + p] = dIy * dIy;
-                    stream[3 * PP + p] = dIx * de;
-                    stream[4 * PP + p] = dIy * de;
-                    stream[5 * PP + p] = dIx;
-                    stream[6 * PP + p] = dIy;
-                    stream[7 * PP + p] = de;
+                    if constexpr (MFMA) {
+                        stream[0 * PS + p] = dIx;
+                        stream[1 * PS + p] = dIy;
+                        stream[2 * PS + p] = -de;
+                    } else {
+                        stream[0 * PP + p] = dIx * dIx;
+                        stream[1 * PP + p] = dIy * dIx;
+                        stream[2 * PP + p] = dIy * dIy;
+                        stream[3 * PP + p] = dIx * de;
+                        stream[4 * PP + p] = dIy * de;
+                        stream[5 * PP + p] = dIx;
+                        stream[6 * PP + p] = dIy;
+                        stream[7 * PP + p] = de;
+                    }
                     esq[p] = e * e;  // :294
                 }
             }
             __syncthreads();
             STAMP(1)
             // ---- 2. ordered accumulation (:284-299) -------------------------------------------
-            if (wave < 3) {
+            if constexpr (MFMA) {
+                if (wave == 0) {
+                    // one dependent MFMA per four pixels; operands prefetched one group of kU ahead
+                    constexpr int kU = 4;
+                    double d = 0.0;
+                    const int M = (P + 3) >> 2, Mfull = P >> 2;  // PP >= 4 * M: reads past P stay inside the arrays
+                    double an[kU], bn[kU];
+                    const double *pa = a_src, *pb = b_src;
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        an[u] = *pa;
+                        bn[u] = *pb;
+                        pa += a_step;
+                        pb += b_step;
+                    }
+                    int m = 0;
+                    for (; m + kU <= Mfull; m += kU) {
+                        double a0[kU], b0[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; u++) {
+                            a0[u] = an[u];
+                            b0[u] = bn[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; u++) {  // next group (may run past Mfull: loaded, never used)
+                            an[u] = *pa;
+                            bn[u] = *pb;
+                            pa += a_step;
+                            pb += b_step;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[u], b0[u], d, 0, 0, 0);
+                    }
+                    // an/bn hold groups m .. m+kU-1
+                    const int rem = Mfull - m;
+#pragma unroll
+                    for (int u = 0; u < kU; u++)
+                        if (u < rem) d = __builtin_amdgcn_mfma_f64_4x4x4f64(an[u], bn[u], d, 0, 0, 0);
+                    if (M > Mfull) {
+                        // last group: pixels past the patch contribute fma(-0.0, 1.0, d) = d exactly
+                        const bool pad = 4 * Mfull + mk >= P;
+                        const double av = a_src[(size_t)Mfull * a_step], bv = b_src[(size_t)Mfull * b_step];
+                        d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
+                    }
+                    // D(q, i, j) sits in lane 16 i + 4 q + j
+                    const int di = lane >> 4, dq = (lane >> 2) & 3, dj = lane & 3;
+                    if (dq == 0) acc[di * 4 + dj] = d;       // H
+                    if (dq == 1 && dj == 0) acc[16 + di] = d;  // b
+                } else {
+                    float c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
+                    if (lane == 0) sh_cost[0] = c;
+                }
+            } else if (wave < 3) {
                 double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
                 if (lr == 0) acc[cid] = s;
             } else {
@@ -466,20 +571,26 @@ __global__ void __launch_bounds__(kBlock) k_track_block(TrackArgs a)
             // ---- 3. solve (:302-319) ------------------------------------------------------------
             if (tid == 0) {
                 double H[4][4], b[4], upd[4];
-                H[0][0] = acc[0];
-                H[1][0] = acc[1];
-                H[1][1] = acc[2];
-                H[2][0] = acc[5];
-                H[2][1] = acc[6];
-                H[2][2] = acc[11];
-                H[3][0] = acc[7];
-                H[3][1] = acc[8];
-                H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
-                H[3][3] = (double)P;       // sum of 1.0*1.0
-                b[0] = acc[3];
-                b[1] = acc[4];
-                b[2] = acc[9];
-                b[3] = acc[10];
+                if constexpr (MFMA) {
+                    for (int r = 0; r < 4; r++)
+                        for (int c = 0; c <= r; c++) H[r][c] = acc[r * 4 + c];
+                    for (int r = 0; r < 4; r++) b[r] = acc[16 + r];
+                } else {
+                    H[0][0] = acc[0];
+                    H[1][0] = acc[1];
+                    H[1][1] = acc[2];
+                    H[2][0] = acc[5];
+                    H[2][1] = acc[6];
+                    H[2][2] = acc[11];
+                    H[3][0] = acc[7];
+                    H[3][1] = acc[8];
+                    H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
+                    H[3][3] = (double)P;       // sum of 1.0*1.0
+                    b[0] = acc[3];
+                    b[1] = acc[4];
+                    b[2] = acc[9];
+                    b[3] = acc[10];
+                }
                 float cost = sh_cost[0];
                 if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
                 double unorm = llt4_solve_norm(H, b, upd);
