@@ -151,11 +151,13 @@ int pagk_sync(pagk_ctx *ctx);
  * context's own; pass NULL to restore. */
 int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
 
-/* Kernel selection: 0 = default (one 4-wave workgroup per feature, DPP-row ordered accumulation;
- * switches to variant 2 for launches larger than the chip holds at once), 1 = reference-shaped
- * one-thread-per-feature kernel (debug / cross-check), 2 = 2-wave workgroups with the ordered
- * accumulation on the matrix pipe (v_mfma_f64_4x4x4f64 chain; half_patch 5, 7 or 10). All three
- * produce bit-identical results. */
+/* Kernel selection.  0 = automatic (default): by launch size, one of
+ *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < ~2500 features)
+ *   - 2-wave workgroup per feature, ordered accumulation as a v_mfma_f64_4x4x4f64 chain  (= 2)
+ *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; highest throughput, >= ~6000 features)
+ * 1 = reference-shaped one-thread-per-feature kernel (debug / cross-check).  2 and 3 force a variant
+ * (half_patch 5, 7 or 10; other sizes fall back to the 4-wave kernel).  Every variant produces
+ * bit-identical results. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 
 /* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,

@@ -46,7 +46,11 @@ struct pagk_ctx {
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
-    int mfma_min_features = 1 << 30;  // auto-selection threshold of the MFMA variant (PAGK_MFMA_MIN)
+    // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
+    // the 4-wave DPP kernel is fastest while every workgroup is resident (its latency is lowest), the
+    // 2-wave MFMA variant from ~2500 features, one wave per feature from ~6000.
+    int mfma_min_features = 2500;  // PAGK_MFMA_MIN
+    int wave_min_features = 6000;  // PAGK_WAVE_MIN
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
@@ -248,9 +252,22 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         // MFMA variant: instantiated for the common patch sizes; chosen explicitly (kernel 2) or,
         // by default, when the launch has more features than can be resident at once
         const bool mfma_ok = a.half == 5 || a.half == 7 || a.half == 10;
-        const bool use_mfma = mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
+        const bool use_wave = mfma_ok && (ctx->kernel == 3 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
+        const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        } else if (use_wave) {
+            // one wavefront per feature (pagk_wave_kernel.h)
+            const size_t lds = track_wave_lds_bytes(a.half);
+            auto launch = [&](auto kern) -> hipError_t {
+                hipLaunchKernelGGL(kern, dim3(n), dim3(64), lds, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e = hipErrorInvalidValue;
+            if (a.half == 5) e = launch(k_track_wave<2, 25>);        // P = 121
+            else if (a.half == 7) e = launch(k_track_wave<4, 1>);    // P = 225
+            else if (a.half == 10) e = launch(k_track_wave<7, 25>);  // P = 441
+            HIPCHK(ctx, e);
         } else if (use_mfma) {
             const size_t lds = track_mfma_lds_bytes(a.half);
             auto launch = [&](auto kern) -> hipError_t {
@@ -462,6 +479,7 @@ int pagk_create(pagk_ctx **out, int device)
     ctx->stream = ctx->own_stream;
     ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
+    if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     for (int k = 0; k < 2; k++) {
         if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
             pagk_destroy(ctx);
@@ -497,7 +515,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
 
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
-    if (!ctx || which < 0 || which > 2) return PAGK_E_ARG;
+    if (!ctx || which < 0 || which > 3) return PAGK_E_ARG;
     ctx->kernel = which;
     return PAGK_OK;
 }

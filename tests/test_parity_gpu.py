@@ -67,6 +67,26 @@ def test_mfma_kernel_on_baseline_configs(ctx, idx, n):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_wave_kernel_matches_golden_vectors(ctx, name):
+    # one wavefront per feature: f32 streams, MFMA chain for H and b, DPP chain for the cost
+    params, inp, exp = load_golden(name)
+    ctx.set_kernel(3)
+    try:
+        got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                        inp["status_in"])
+    finally:
+        ctx.set_kernel(0)
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("idx,n", [(1, 1000), (3, 6000)])
+def test_wave_kernel_on_baseline_configs(ctx, idx, n):
+    w = synth.config(idx, n=n)
+    got, ref = run_both(ctx, params_for(w), w, kernel=3)
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+
+
 @pytest.mark.parametrize("idx,n", [(0, 500), (1, 1000), (2, 2000), (3, 3000)])
 def test_baseline_configs_against_oracle(ctx, idx, n):
     # BASELINE.json configs (synthetic stand-ins); 21x21 patch, 30 iterations

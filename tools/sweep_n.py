@@ -9,7 +9,7 @@ for cfg, ns in ((1, (250, 500, 1000, 1500, 2000, 3000, 4000, 8000)), (3, (20000,
         w = synth.config(cfg, n=n)
         p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
         row = [f"cfg{cfg} n={n:6d} active={w.n_active:6d}"]
-        for k in (0, 2):
+        for k in (0, 2, 3):
             ctx.set_kernel(k)
             ts = []
             for _ in range(4):
