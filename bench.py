@@ -76,6 +76,8 @@ def main() -> int:
     ap.add_argument("--features-per-gpu", type=int, default=1000)
     ap.add_argument("--config", type=int, default=1, help="synth.config index (1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-path and multi-camera side measurements")
+    ap.add_argument("--cameras", type=int, default=4, help="independent streams of the multi-camera side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -148,6 +150,52 @@ def main() -> int:
 
     res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (a) the drop-in call itself: pagk_track on HOST buffers -- two frame uploads, pyramids, per-feature
+        #     arrays in, results out, synchronous.  PCIe-inclusive; never `value`.
+        hctx = capi.Context(local_rank)
+        for _ in range(5):
+            hctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        t1 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            hctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        th = (time.perf_counter() - t1) / reps
+        hctx.close()
+        extras["host_buffer_path"] = {"value": n_active_total / th, "unit": "features/s", "ms_per_call": th * 1e3,
+                                      "what": "pagk_track(): both frames + feature arrays over PCIe, pyramids of both "
+                                              "frames, tracking, results back; synchronous"}
+        # (b) multi-camera: C independent frame streams in flight on one GPU (BASELINE configs[4] shape).
+        #     Steps of DIFFERENT cameras do not depend on each other, so their launches overlap and fill the
+        #     tail of each other's slowest features.  Reported beside `value`, not as `value`.
+        C = max(1, args.cameras)
+        cams = []
+        for c in range(C):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                r2 = runtime.ResidentTracker(p, device=local_rank)
+                r2.load_pair(w.img_ref, w.img_cur)
+                r2.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+            cams.append((st, r2))
+        def cam_steps(k):
+            for _ in range(k):
+                for st, r2 in cams:
+                    with torch.cuda.stream(st):
+                        r2.step()
+        cam_steps(5)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ksteps = max(20, args.steps // 2)
+        cam_steps(ksteps)
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - t1
+        extras["multi_camera"] = {"value": n_active_total * C * ksteps / tc, "unit": "features/s", "cameras": C,
+                                  "steps_per_camera": ksteps,
+                                  "what": f"{C} independent streams of the same workload in flight on one GPU"}
+        for _, r2 in cams:
+            r2.close()
+
     if rank == 0:
         b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
         achieved = n_active_local * b_alg / (kernel_ms * 1e-3) / 1e9
@@ -181,6 +229,7 @@ def main() -> int:
         it = res["iters"][:n_total]
         line["mean_iters_per_feature"] = float(it[w.status_in > 0].mean())
         line["max_iters_per_feature"] = int(it.max())
+        line.update(extras)
 
         if not args.no_cpu_baseline and world == 1:
             from oracle import pagk_oracle as orc   # cpu_baseline leg: the only use of oracle/ here

@@ -27,7 +27,7 @@ class ResidentTracker:
         torch.cuda.set_device(self.dev)
         self.ctx = capi.Context(device)
         # run on torch's current stream so that torch.cuda.Event / torch.distributed order with us
-        self.main = torch.cuda.current_stream(self.dev)
+        self.main = torch.cuda.current_stream(self.dev)   # the stream current at construction time
         self.ctx.set_stream(self.main.cuda_stream)
         # side stream: the NEXT frame's pyramid is built while the current pair is being tracked (a
         # new frame's pyramid does not depend on any tracking result)
