@@ -250,6 +250,82 @@ __device__ __forceinline__ double llt4_solve_norm(double (&M)[4][4], const doubl
     return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
 }
 
+// The same solve spread over four lanes (l = 0..3 of one wave, all holding the same H and b): per
+// Cholesky column the divides of the rows below the pivot and the forward-substitution divide of that
+// column are ONE divide instruction executed by four lanes instead of up to four sequences in one lane;
+// results travel by v_readlane.  Operation for operation the arithmetic of llt4_solve_norm above (the
+// serial form stays in k_track_thread as the cross-check).  Critical path: 4 sqrt + 8 divides.
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double llt4_solve_norm_lanes(const double (&M)[4][4], const double (&b)[4], int l,
+                                                        double (&x)[4])
+{
+    const double H00 = M[0][0], H10 = M[1][0], H11 = M[1][1], H20 = M[2][0], H21 = M[2][1], H22 = M[2][2];
+    const double H30 = M[3][0], H31 = M[3][1], H32 = M[3][2], H33 = M[3][3];
+    // column 0: lane 0 -> r0 = b0 / d0, lane i -> L(i,0) = H(i,0) / d0
+    const bool ok0 = !(H00 <= 0.0);
+    const double sq0 = sqrt(H00);
+    const double d0 = ok0 ? sq0 : H00;
+    const double n0 = l == 0 ? b[0] : (l == 1 ? H10 : (l == 2 ? H20 : H30));
+    const double q0 = n0 / d0;
+    const double own0 = (l == 0 || ok0) ? q0 : n0;
+    double r0 = lane_bcast(own0, 0);
+    const double L10 = lane_bcast(own0, 1), L20 = lane_bcast(own0, 2), L30 = lane_bcast(own0, 3);
+    // column 1: lane 1 -> r1, lanes 2, 3 -> L(i,1)
+    const double x1 = H11 - L10 * L10;
+    const bool ok1 = ok0 && !(x1 <= 0.0);
+    const double sq1 = sqrt(x1);
+    const double d1 = ok1 ? sq1 : H11;
+    const double h1 = l == 2 ? H21 : H31;
+    const double n1 = l == 1 ? b[1] - L10 * r0 : h1 - (l == 2 ? L20 : L30) * L10;
+    const double q1 = n1 / d1;
+    const double own1 = (l == 1 || ok1) ? q1 : h1;
+    double r1 = lane_bcast(own1, 1);
+    const double L21 = lane_bcast(own1, 2), L31 = lane_bcast(own1, 3);
+    // column 2: lane 2 -> r2, lane 3 -> L(3,2)
+    double s = L20 * L20;
+    s += L21 * L21;
+    const double x2 = H22 - s;
+    const bool ok2 = ok1 && !(x2 <= 0.0);
+    const double sq2 = sqrt(x2);
+    const double d2 = ok2 ? sq2 : H22;
+    s = L30 * L20;
+    s += L31 * L21;
+    const double n2 = l == 2 ? b[2] - (L20 * r0 + L21 * r1) : H32 - s;
+    const double q2 = n2 / d2;
+    const double own2 = (l == 2 || ok2) ? q2 : H32;
+    double r2 = lane_bcast(own2, 2);
+    const double L32 = lane_bcast(own2, 3);
+    // column 3
+    s = L30 * L30;
+    s += L31 * L31;
+    s += L32 * L32;
+    const double x3 = H33 - s;
+    const bool ok3 = ok2 && !(x3 <= 0.0);
+    const double sq3 = sqrt(x3);
+    const double d3 = ok3 ? sq3 : H33;
+    double r3 = (b[3] - (L30 * r0 + (L31 * r1 + L32 * r2))) / d3;
+    // L^T x = y  (sequential by nature; every lane computes it)
+    r3 /= d3;
+    r2 -= L32 * r3;
+    r2 /= d2;
+    r1 -= L21 * r2 + L31 * r3;
+    r1 /= d1;
+    r0 -= (L10 * r1 + L20 * r2) + L30 * r3;
+    r0 /= d0;
+    x[0] = r0;
+    x[1] = r1;
+    x[2] = r2;
+    x[3] = r3;
+    return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
+}
+
 // Gyro regularisation penalty, src/patch_match.cpp:302-314.  Adds to H (lower triangle
 // only: LLT reads nothing else), b and cost.
 __device__ __forceinline__ void add_penalty(const TrackArgs &a, float dx, float dy, double (&H)[4][4],

@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
             __syncthreads();
             STAMP(2)
             // ---- 3. solve (:302-319) ------------------------------------------------------------
-            if (tid == 0) {
+            if (tid < 4) {
                 double H[4][4], b[4], upd[4];
                 if constexpr (MFMA) {
                     for (int r = 0; r < 4; r++)
@@ -593,13 +593,16 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
                 }
                 float cost = sh_cost[0];
                 if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
-                double unorm = llt4_solve_norm(H, b, upd);
-                sh_upd[0] = upd[0];
-                sh_upd[1] = upd[1];
-                sh_upd[2] = upd[2];
-                sh_upd[3] = upd[3];
-                sh_upd[4] = unorm;
-                sh_cost[1] = cost;
+                // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
+                double unorm = llt4_solve_norm_lanes(H, b, tid, upd);
+                if (tid == 0) {
+                    sh_upd[0] = upd[0];
+                    sh_upd[1] = upd[1];
+                    sh_upd[2] = upd[2];
+                    sh_upd[3] = upd[3];
+                    sh_upd[4] = unorm;
+                    sh_cost[1] = cost;
+                }
             }
             __syncthreads();
             STAMP(3)

@@ -219,20 +219,23 @@ __global__ void __launch_bounds__(64, 4) k_track_wave(TrackArgs a)
             }
             __syncthreads();
             // ---- 4. solve (:302-319) ------------------------------------------------------------
-            if (lane == 0) {
+            if (lane < 4) {
                 double H[4][4], b[4], upd[4];
                 for (int r = 0; r < 4; r++)
                     for (int c = 0; c <= r; c++) H[r][c] = acc[r * 4 + c];
                 for (int r = 0; r < 4; r++) b[r] = acc[16 + r];
                 float cost = sh_cost[0];
                 if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
-                double unorm = llt4_solve_norm(H, b, upd);
-                sh_upd[0] = upd[0];
-                sh_upd[1] = upd[1];
-                sh_upd[2] = upd[2];
-                sh_upd[3] = upd[3];
-                sh_upd[4] = unorm;
-                sh_cost[1] = cost;
+                // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
+                double unorm = llt4_solve_norm_lanes(H, b, lane, upd);
+                if (lane == 0) {
+                    sh_upd[0] = upd[0];
+                    sh_upd[1] = upd[1];
+                    sh_upd[2] = upd[2];
+                    sh_upd[3] = upd[3];
+                    sh_upd[4] = unorm;
+                    sh_cost[1] = cost;
+                }
             }
             __syncthreads();
             // ---- 5. update + termination (:322-344) -----------------------------------------------

@@ -141,6 +141,31 @@ def test_empty_and_all_skipped(ctx):
     assert not got["status"][:w.n].any() and np.array_equal(got["pt_un"][:w.n], w.pt_init)
 
 
+def test_garbage_coordinates_are_safe_and_defined(ctx):
+    # NaN / inf / far-outside points: the reference would index with int(NaN) (undefined).  This
+    # implementation and the oracle define it (NaN -> 0, everything else clamps), so the kernels must not
+    # fault and must still agree with the oracle, on every variant.
+    w = synth.make_workload("garbage", 320, 240, 64, seed=0x5EED0800, half_patch=10, iterations=30, pyramids=3)
+    bad = [np.nan, np.inf, -np.inf, 1e30, -1e30, 1e9, -5000.0, 319.9999, -0.0]
+    pr, pi, A = w.pt_ref.copy(), w.pt_init.copy(), w.affine.copy()
+    for k, v in enumerate(bad):
+        pr[2 * k, 0] = v          # garbage reference point
+        pi[2 * k + 1, 1] = v      # garbage predicted point
+    A[40] = [np.nan, 0, 0, 1]
+    A[41] = [1e20, -1e20, 3, 4]
+    A[42] = 0
+    p = params_for(w)
+    with np.errstate(all="ignore"):
+        ref = orc.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
+    for k in (0, 1, 2, 3):
+        ctx.set_kernel(k)
+        try:
+            got = ctx.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
+        finally:
+            ctx.set_kernel(0)
+        assert_parity(got, ref, w.n, exact=True, what=f"garbage inputs, kernel {k}")
+
+
 def test_non_contiguous_rows(ctx):
     # cv::Mat with step > cols (an ROI): the bytes between cols and step are defined as 0
     w = synth.make_workload("roi", 200, 120, 40, seed=0x5EED0400, half_patch=5, iterations=10, pyramids=2,
