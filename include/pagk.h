@@ -165,6 +165,18 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms);
 
 /* ---- producer / consumer rows next to the path ----------------------------- */
+/* GyroAidedTracker::GyroPredictFeatures + GyroPredictOnePixel, PIXEL_AWARE_PREDICTION
+ * (src/gyro_aided_tracker.cpp:118-185,194-231), on the device: predicted point (un-distorted and
+ * distorted), border status and the 2x2 affine A = C B^T (B B^T)^-1 from the four predicted patch corners.
+ * Produces exactly the arrays pagk_track_device consumes, so prediction -> tracking needs no host
+ * round trip.  All pointers are device pointers; camera model from params (fx fy cx cy dist_coef);
+ * KRKinv = mK * mRcl * mK^-1 (3x3 row-major, :518), r3 = third row of mRcl.  Where a prediction leaves
+ * the image the outputs keep the tracker's initial state: status 0, points (0,0), affine untouched.
+ * d_affine may be NULL.  Asynchronous on the context stream. */
+int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                             const float *KRKinv, const float *r3, int32_t n, const float *d_pt_ref_un,
+                             float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status, float *d_affine);
+
 /* Tracker-side post-filter, GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined
  * Step 3 (src/gyro_aided_tracker.cpp:289-341): thresholds from the mean pixel
  * error, final inlier mask, survivors' points copied into pt_predict(_un).

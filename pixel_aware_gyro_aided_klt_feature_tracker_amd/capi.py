@@ -147,6 +147,8 @@ def declare(lib) -> None:
     lib.pagk_set_kernel.argtypes = [vp, i32]
     lib.pagk_last_kernel_ms.restype = C.c_int
     lib.pagk_last_kernel_ms.argtypes = [vp, _P(C.c_float), _P(C.c_float)]
+    lib.pagk_gyro_predict_device.restype = C.c_int
+    lib.pagk_gyro_predict_device.argtypes = [vp, _P(Params), i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pagk_post_filter.restype = C.c_int
     lib.pagk_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
 
@@ -155,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
-    "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter",
+    "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
 ]
 
 
@@ -250,6 +252,15 @@ class Context:
         self._check(self.lib.pagk_track_device(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
                                                _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o)),
                     "pagk_track_device")
+
+    def gyro_predict_device(self, params: Params, width: int, height: int, KRKinv, r3, n: int, d_pt_ref,
+                            d_pt_predict_un, d_pt_predict, d_status, d_affine):
+        K = np.ascontiguousarray(KRKinv, np.float32)
+        r = np.ascontiguousarray(r3, np.float32)
+        self._check(self.lib.pagk_gyro_predict_device(self.h, C.byref(params), width, height, K.ctypes.data,
+                                                      r.ctypes.data, n, _ptr(d_pt_ref), _ptr(d_pt_predict_un),
+                                                      _ptr(d_pt_predict), _ptr(d_status), _ptr(d_affine)),
+                    "pagk_gyro_predict_device")
 
     def sync(self):
         self._check(self.lib.pagk_sync(self.h), "pagk_sync")

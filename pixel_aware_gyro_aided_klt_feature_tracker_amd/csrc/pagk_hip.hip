@@ -694,6 +694,43 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
                              ctx->slots[5]);
 }
 
+int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                             const float *KRKinv, const float *r3, int32_t n, const float *d_pt_ref_un,
+                             float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status, float *d_affine)
+{
+    if (!ctx || !params || !KRKinv || !r3 || n < 0 || width < 1 || height < 1) return PAGK_E_ARG;
+    if (params->half_patch < 1 || params->half_patch > PAGK_MAX_HALF_PATCH) return PAGK_E_ARG;
+    if (n > 0 && (!d_pt_ref_un || !d_pt_predict_un || !d_pt_predict || !d_status)) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PredictArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n, a.width = width, a.height = height;
+    a.half = (float)params->half_patch;
+    a.fx = params->fx, a.fy = params->fy, a.cx = params->cx, a.cy = params->cy;
+    a.fx_inv = (float)(1.0 / (double)params->fx);  // src/gyro_aided_tracker.cpp:66
+    a.fy_inv = (float)(1.0 / (double)params->fy);
+    a.k1 = params->dist_coef[0], a.k2 = params->dist_coef[1], a.p1 = params->dist_coef[2], a.p2 = params->dist_coef[3];
+    a.k3 = params->n_dist_coef == 5 ? params->dist_coef[4] : 0.0f;
+    for (int k = 0; k < 6; k++) a.K[k] = KRKinv[k];
+    a.r31 = r3[0], a.r32 = r3[1], a.r33 = r3[2];
+    // (B B^T)^-1 for B = +-h corners (:73-78): B B^T = diag(4h^2); cv::Mat::inv of a 2x2 goes through
+    // the double determinant
+    const float m00 = 4.0f * a.half * a.half;
+    const double det = (double)m00 * m00, dinv = det != 0 ? 1. / det : 0;
+    a.inv00 = (float)(m00 * dinv);
+    a.inv01 = (float)(-0.0f * dinv);
+    a.pt_ref = d_pt_ref_un;
+    a.pt_un = d_pt_predict_un;
+    a.pt_dist = d_pt_predict;
+    a.status = d_status;
+    a.affine = d_affine;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gyro_predict, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PAGK_OK;
+}
+
 // GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined, Step 3,
 // src/gyro_aided_tracker.cpp:289-341.  O(n) host arithmetic on the gathered results.
 int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm, const double *pix_err,

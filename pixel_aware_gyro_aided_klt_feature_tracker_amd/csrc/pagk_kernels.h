@@ -115,6 +115,82 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(PyrArgs a)
     }
 }
 
+// ---- GyroPredictFeatures (src/gyro_aided_tracker.cpp:118-185,194-231), one thread per feature ----
+struct PredictArgs {
+    int n, width, height;
+    float half;  // (float)mHalfPatchSize
+    float fx, fy, cx, cy, fx_inv, fy_inv, k1, k2, p1, p2, k3;
+    float K[6];            // rows 0 and 1 of mKRKinv
+    float r31, r32, r33;   // third row of mRcl
+    float inv00, inv01;    // (B B^T)^-1 = [[inv00, inv01], [inv01, inv00]] for the +-h corner matrix
+    const float *pt_ref;
+    float *pt_un, *pt_dist, *affine;
+    uint8_t *status;
+};
+
+// GyroPredictOnePixel, PIXEL_AWARE_PREDICTION (:205-231)
+__device__ __forceinline__ void predict_one(const PredictArgs &a, float rx, float ry, float &ux, float &uy, float &dxo,
+                                            float &dyo)
+{
+    float x_normal = (rx - a.cx) * a.fx_inv;  // :209-210
+    float y_normal = (ry - a.cy) * a.fy_inv;
+    float lambda = (float)(1.0 / (double)(a.r31 * x_normal + a.r32 * y_normal + a.r33));  // :216
+    float pt_x = (a.K[0] * rx + a.K[1] * ry + a.K[2]) * lambda;                            // :217
+    float pt_y = (a.K[3] * rx + a.K[4] * ry + a.K[5]) * lambda;                            // :218
+    float x = (pt_x - a.cx) * a.fx_inv;                                                    // :221-222
+    float y = (pt_y - a.cy) * a.fy_inv;
+    float r2 = x * x + y * y;
+    float r4 = r2 * r2;
+    float r6 = r4 * r2;
+    float xd = x * (1 + a.k1 * r2 + a.k2 * r4 + a.k3 * r6) + 2 * a.p1 * x * y + a.p2 * (r2 + 2 * x * x);
+    float yd = y * (1 + a.k1 * r2 + a.k2 * r4 + a.k3 * r6) + a.p1 * (r2 + 2 * y * y) + 2 * a.p2 * x * y;
+    ux = pt_x;
+    uy = pt_y;
+    dxo = a.fx * xd + a.cx;  // :229-230
+    dyo = a.fy * yd + a.cy;
+}
+
+__global__ void __launch_bounds__(256) k_gyro_predict(PredictArgs a)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    // Initialize() state where the loop `continue`s (:92-95, :131-135)
+    a.status[i] = 0;
+    a.pt_un[2 * i] = a.pt_un[2 * i + 1] = 0.0f;
+    a.pt_dist[2 * i] = a.pt_dist[2 * i + 1] = 0.0f;
+    const float rx = a.pt_ref[2 * i], ry = a.pt_ref[2 * i + 1];
+    float ux, uy, dxs, dys;
+    predict_one(a, rx, ry, ux, uy, dxs, dys);
+    const float W = (float)a.width, H = (float)a.height;
+    if (ux < 0 || ux >= W || uy < 0 || uy >= H) return;      // :131
+    if (dxs < 0 || dxs >= W || dys < 0 || dys >= H) return;  // :134
+    a.pt_un[2 * i] = ux;
+    a.pt_un[2 * i + 1] = uy;
+    a.pt_dist[2 * i] = dxs;
+    a.pt_dist[2 * i + 1] = dys;
+    a.status[i] = 1;
+    if (!a.affine) return;
+    // four corners (:148-160), then A = C B^T (B B^T)^-1 (:166-167): float products accumulated in
+    // double per Mat product, narrowed after each product (cv::Mat gemm on small CV_32F matrices)
+    const float cxs[4] = {-a.half, a.half, -a.half, a.half}, cys[4] = {-a.half, -a.half, a.half, a.half};
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float cux, cuy, t0, t1;
+        predict_one(a, rx + cxs[j], ry + cys[j], cux, cuy, t0, t1);
+        const float Cx = cux - ux, Cy = cuy - uy;
+        s00 += (double)Cx * cxs[j];
+        s01 += (double)Cx * cys[j];
+        s10 += (double)Cy * cxs[j];
+        s11 += (double)Cy * cys[j];
+    }
+    const float t00 = (float)s00, t01 = (float)s01, t10 = (float)s10, t11 = (float)s11;
+    a.affine[4 * i + 0] = (float)((double)t00 * a.inv00 + (double)t01 * a.inv01);
+    a.affine[4 * i + 1] = (float)((double)t00 * a.inv01 + (double)t01 * a.inv00);
+    a.affine[4 * i + 2] = (float)((double)t10 * a.inv00 + (double)t11 * a.inv01);
+    a.affine[4 * i + 3] = (float)((double)t10 * a.inv01 + (double)t11 * a.inv00);
+}
+
 // ---- shared epilogue: SetMatcher + DistortPoints for one feature --------------------------------
 __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
                                               float lastCost, int level0_ran, float ncc, int iters)

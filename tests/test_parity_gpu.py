@@ -246,6 +246,41 @@ def test_device_resident_path_matches_host_path(ctx):
     assert_parity(dev, host, w.n, exact=True)
 
 
+def test_gyro_predict_on_device_then_track_without_host_round_trip(ctx):
+    # row f1: GyroPredictFeatures on the device feeds pagk_track_device directly
+    cam = synth.EUROC
+    w = synth.config(1, n=1500, edge_fraction=0.1)
+    Rp = synth.rodrigues(np.array((0.004, -0.003, 0.006))) @ synth.rodrigues(np.array((0.5, -1.0, 2.0)) * 0.05)
+    K32 = cam.K.astype(np.float32)
+
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    KRK = mul(mul(K32, Rp.astype(np.float32)), np.linalg.inv(K32.astype(np.float64)).astype(np.float32))
+    r3 = Rp.astype(np.float32)[2]
+    p = params_for(w)
+    pu, pd, st, A = orc.gyro_predict(p, 752, 480, w.half_patch, KRK, r3, w.pt_ref)
+    dev = torch.device("cuda", 0)
+    d_ref = torch.from_numpy(w.pt_ref).to(dev)
+    d_pu = torch.full((w.n, 2), 7.0, device=dev)
+    d_pd = torch.full((w.n, 2), 7.0, device=dev)
+    d_st = torch.full((w.n,), 9, dtype=torch.uint8, device=dev)
+    d_A = torch.zeros((w.n, 4), device=dev)
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.ctx.gyro_predict_device(p, 752, 480, KRK, r3, w.n, d_ref, d_pu, d_pd, d_st, d_A)
+    out = distributed.alloc_device_outputs(w.n, dev)
+    rt.ctx.track_device(p, 0, 1, w.n, d_ref, d_pu, d_A, d_st, out)
+    torch.cuda.synchronize()
+    assert 0 < int(st.sum()) < w.n                              # the edge set produces rejects
+    assert np.array_equal(d_st.cpu().numpy(), st)
+    assert np.array_equal(d_pu.cpu().numpy(), pu) and np.array_equal(d_pd.cpu().numpy(), pd)
+    assert np.array_equal(d_A.cpu().numpy()[st > 0], A[st > 0])
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, pu, A, st, nthreads=16)
+    got = {k: out[k].cpu().numpy() for k, _, _ in distributed.FIELDS}
+    rt.close()
+    assert_parity(got, ref, w.n, exact=True, what="device predict -> device track")
+
+
 # ---- full-size properties (sizes the oracle would take too long to check in full) ---------------
 def test_full_size_properties_1080p_20000(ctx):
     w = synth.config(3)  # 1920x1080, 20000 keypoints
