@@ -285,9 +285,15 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             const int nr = (P + kBlock - 1) / kBlock, tail = P % 32;
             const size_t lds = track_block_lds_bytes(a.half);
             auto launch = [&](auto kern) -> hipError_t {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
+                // > 64 KB of dynamic LDS (h >= 14) needs the attribute; set it once per kernel and device
+                static thread_local const void *configured[16] = {};
+                const void *fn = reinterpret_cast<const void *>(kern);
+                const int slot = ctx->device & 15;
+                if (lds > 48 * 1024 && configured[slot] != fn) {
+                    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    configured[slot] = fn;
+                }
                 hipLaunchKernelGGL(kern, dim3(n), dim3(kBlock), lds, ctx->stream, a);
                 return hipGetLastError();
             };

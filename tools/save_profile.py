@@ -1,0 +1,21 @@
+"""Copy the summaries of gpurun_out/prof_<tag> (tools/profile.sh) into profiles/<tag>/."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1]
+src, dst = f"gpurun_out/prof_{tag}", f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"{dst}/kernel_stats.csv")
+if os.path.exists(f"gpurun_out/bench_{tag}.json"):
+    shutil.copy(f"gpurun_out/bench_{tag}.json", f"{dst}/bench.json")
+out = {}
+for part in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(f"{src}/{part}/*/*_counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, d in agg.items():
+            if "pagk" in k:
+                for c, v in d.items():
+                    out.setdefault(k, {})[c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
+json.dump(out, open(f"{dst}/pmc_summary.json", "w"), indent=1)
+for k, d in out.items():
+    print(k, {c: round(v["mean"]) for c, v in d.items()})
