@@ -25,6 +25,21 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(capi.EXPORTED_SYMBOLS)
 
 
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    # include/pagk.h must compile as C, and a C program must be able to drive the library
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                    os.path.join(inc, "pagk.h")], check=True)
+    exe = str(tmp_path / "c_abi_smoke")
+    pkg = capi.PKG_DIR
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+                    "-o", exe, "-L", pkg, "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
 def test_version_errors_defaults(built):
     lib = capi.load()
     assert lib.pagk_version() == 100
