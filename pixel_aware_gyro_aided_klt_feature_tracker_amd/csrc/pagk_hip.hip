@@ -371,6 +371,8 @@ int upload_level0(pagk_ctx *ctx, FrameSlot &s, const pagk_image *img)
 int check_image(const pagk_image *im)
 {
     if (!im || !im->data || im->width < 1 || im->height < 1 || im->step < im->width) return PAGK_E_ARG;
+    // the samplers index with 24-bit multiplies and 32-bit element offsets
+    if (im->width >= (1 << 24) || im->height >= (1 << 24) || (int64_t)im->width * im->height >= (1ll << 31)) return PAGK_E_ARG;
     return PAGK_OK;
 }
 
@@ -579,6 +581,7 @@ int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32
 {
     if (!ctx || slot < 0 || slot >= kUserSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
     if (!d_data || width < 1 || height < 1 || step < width) return PAGK_E_ARG;
+    if (width >= (1 << 24) || height >= (1 << 24) || (int64_t)width * height >= (1ll << 31)) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     FrameSlot &s = ctx->slots[slot];
     s.valid = false;
