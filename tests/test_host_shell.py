@@ -87,3 +87,77 @@ def test_shell_track_features_end_to_end(built, type_):
     keep = st > 0
     assert np.array_equal(out["pt_predict_un"][keep], ref["pt_un"][:n][keep])
     host_api.load().pagk_tracker_release()
+
+
+@pytest.mark.gpu
+def test_cpp_demo_loop_over_a_sequence(built, tmp_path):
+    """examples/track_sequence.cpp: the reference's per-frame loop (tracked points become the next
+    frame's keypoints) over 5 synthetic frames, against the same loop done with the oracle."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = capi.PKG_DIR
+    exe = str(tmp_path / "track_sequence")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), os.path.join(root, "examples", "track_sequence.cpp"),
+                    "-o", exe, "-L", pkg, "-l:libpagk_tracker.so", "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    cam = synth.D435I
+    rng = synth.SplitMix64(0x5EED0900)
+    tex = synth.Texture(rng)
+    W, H, NF, NK = 320, 240, 5, 150
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    K = cam.K
+    Kinv = np.linalg.inv(K)
+    step = synth.rodrigues(np.array((0.02, -0.015, 0.04)))
+    imgs, Rs, Racc = [], [], np.eye(3)
+    for k in range(NF):
+        Hk = K @ Racc @ Kinv
+        Hi = np.linalg.inv(Hk)
+        den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+        sx = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den
+        sy = (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
+        imgs.append(np.clip(np.rint((1.0 + 0.01 * k) * tex(sx, sy) + k), 0, 255).astype(np.uint8))
+        if k:
+            Rs.append(step.astype(np.float32))
+        Racc = step @ Racc
+    u = rng.uniform(2 * NK)
+    kp = np.stack([40 + u[0::2] * (W - 80), 40 + u[1::2] * (H - 80)], axis=1).astype(np.float32)
+    K32 = K.astype(np.float32)
+    path = str(tmp_path / "seq.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", NF, W, H, NK))
+        f.write(K32.tobytes())
+        f.write(np.asarray(cam.dist[:4], np.float32).tobytes())
+        for im in imgs:
+            f.write(im.tobytes())
+        f.write(kp.tobytes())
+        for R in Rs:
+            f.write(R.tobytes())
+    r = subprocess.run([exe, path, "5", "10", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+
+    # the same loop with the oracle (prediction + PatchMatch + post-filter)
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    Kinv32 = np.linalg.inv(K32.astype(np.float64)).astype(np.float32)
+    p = capi.make_params(half_patch=5, iterations=10, pyramids=3, has_gyro=True, camera=cam)
+    keys, checksum, want = kp.copy(), 0.0, []
+    for k in range(1, NF):
+        KRK = mul(mul(K32, Rs[k - 1]), Kinv32)
+        pu, pd, st, A = orc.gyro_predict(p, W, H, 5, KRK, Rs[k - 1][2], keys)
+        out = orc.track(p, imgs[k - 1], imgs[k], keys, pu, A, st)
+        n = keys.shape[0]
+        n_ok, mask, pp, ppu = orc.post_filter(5, out["status"][:n], out["pix_err"][:n], out["dist_pred"][:n],
+                                              out["pt_dist"][:n], out["pt_un"][:n])
+        want.append(f"pair {k} tracked {n_ok} of {n}")
+        keep = mask > 0
+        nxt = out["pt_un"][:n][keep]
+        checksum += float(np.sum(nxt[:, 0].astype(np.float64) + 2.0 * nxt[:, 1].astype(np.float64)))
+        keys = np.ascontiguousarray(nxt)
+    assert lines[:-1] == want, (lines, want)
+    surv, _, cs = lines[-1].split()[1], lines[-1].split()[2], float(lines[-1].split()[3])
+    assert int(surv) == keys.shape[0] and keys.shape[0] > 0.7 * NK
+    assert abs(cs - checksum) <= 1e-3 * max(1.0, abs(checksum)) * 1e-3
