@@ -154,7 +154,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
 /* Kernel selection.  0 = automatic (default): by launch size, one of
  *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < ~2500 features)
  *   - 2-wave workgroup per feature, ordered accumulation as a v_mfma_f64_4x4x4f64 chain  (= 2)
- *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; highest throughput, >= ~6000 features)
+ *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; highest throughput, >= ~10000 features)
  * 1 = reference-shaped one-thread-per-feature kernel (debug / cross-check).  2 and 3 force a variant
  * (half_patch 5, 7 or 10; other sizes fall back to the 4-wave kernel).  Every variant produces
  * bit-identical results. */

@@ -48,9 +48,9 @@ struct pagk_ctx {
     int kernel = 0;
     // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
     // the 4-wave DPP kernel is fastest while every workgroup is resident (its latency is lowest), the
-    // 2-wave MFMA variant from ~2500 features, one wave per feature from ~6000.
-    int mfma_min_features = 2500;  // PAGK_MFMA_MIN
-    int wave_min_features = 6000;  // PAGK_WAVE_MIN
+    // 2-wave MFMA variant from ~2500 features, one wave per feature from ~10000.
+    int mfma_min_features = 2500;   // PAGK_MFMA_MIN
+    int wave_min_features = 10000;  // PAGK_WAVE_MIN
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
