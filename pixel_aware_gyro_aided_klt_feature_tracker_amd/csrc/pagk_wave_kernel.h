@@ -21,6 +21,10 @@
 #include "pagk_chain_asm.h"
 #include "pagk_device.h"
 
+#ifndef PAGK_WAVE_OCC
+#define PAGK_WAVE_OCC 4  // waves per SIMD the register allocation targets
+#endif
+
 namespace pagk {
 
 __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
@@ -39,7 +43,7 @@ __host__ __device__ inline size_t track_wave_lds_bytes(int half)
 }
 
 template <int NR, int TAIL>
-__global__ void __launch_bounds__(64, 4) k_track_wave(TrackArgs a)
+__global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int i = blockIdx.x;
