@@ -141,6 +141,34 @@ def test_empty_and_all_skipped(ctx):
     assert not got["status"][:w.n].any() and np.array_equal(got["pt_un"][:w.n], w.pt_init)
 
 
+def test_null_initial_points_and_five_distortion_coefficients(ctx):
+    # (1) !mbHasGyroPredictInitial with no predicted points at all: pt_init = NULL -> the reference points
+    #     are both the initial guess (:88) and the "predicted" points of the distance output (:384)
+    w = synth.make_workload("null", 320, 240, 60, seed=0x5EED0A00, half_patch=5, iterations=10, pyramids=3,
+                            motion="translation", has_gyro=False, camera=synth.D435I)
+    p = params_for(w)
+    got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, None, w.affine, w.status_in)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, None, w.affine, w.status_in)
+    assert_parity(got, ref, w.n, exact=True, what="pt_init = NULL")
+    ref2 = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_ref.copy(), w.affine, w.status_in)
+    assert_parity(got, ref2, w.n, exact=True, what="pt_init = NULL == pt_ref")
+    # (2) mDistCoef.total() == 5 (k3 used, src/utils.cpp:57) vs 4 (k3 ignored even if present)
+    cam5 = synth.Camera(394.56, 395.21, 160.3, 121.2, (-0.28, 0.074, 0.0002, 1.7e-5, 0.031))
+    w5 = synth.make_workload("k3", 320, 240, 60, seed=0x5EED0A01, half_patch=5, iterations=10, pyramids=3, camera=cam5)
+    p5 = params_for(w5)
+    assert p5.n_dist_coef == 5
+    got5 = ctx.track(p5, w5.img_ref, w5.img_cur, w5.pt_ref, w5.pt_init, w5.affine, w5.status_in)
+    ref5 = orc.track(p5, w5.img_ref, w5.img_cur, w5.pt_ref, w5.pt_init, w5.affine, w5.status_in)
+    assert_parity(got5, ref5, w5.n, exact=True, what="5 distortion coefficients")
+    p4 = params_for(w5)
+    p4.n_dist_coef = 4
+    got4 = ctx.track(p4, w5.img_ref, w5.img_cur, w5.pt_ref, w5.pt_init, w5.affine, w5.status_in)
+    ref4 = orc.track(p4, w5.img_ref, w5.img_cur, w5.pt_ref, w5.pt_init, w5.affine, w5.status_in)
+    assert_parity(got4, ref4, w5.n, exact=True, what="k3 ignored when 4 coefficients")
+    assert not np.array_equal(got4["pt_dist"][:w5.n], got5["pt_dist"][:w5.n])
+    assert np.array_equal(got4["pt_un"][:w5.n], got5["pt_un"][:w5.n])
+
+
 def test_garbage_coordinates_are_safe_and_defined(ctx):
     # NaN / inf / far-outside points: the reference would index with int(NaN) (undefined).  This
     # implementation and the oracle define it (NaN -> 0, everything else clamps), so the kernels must not
