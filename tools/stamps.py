@@ -8,7 +8,7 @@ import torch
 import __graft_entry__ as g
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
 
-lib_path = os.path.join(ROOT, "gpurun_out", "libpagk_hip_stamps.so")
+lib_path = os.path.join(ROOT, "tools", "bin", "libpagk_hip_stamps.so")
 if not os.path.exists(lib_path):
     subprocess.run(["/opt/rocm/bin/hipcc", *g.HIPCC_FLAGS, "-DPAGK_STAMPS", "-o", lib_path,
                     os.path.join(g.CSRC, "pagk_hip.hip")], check=True)
