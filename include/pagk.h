@@ -186,6 +186,36 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
                      const float *pt_pm_un, uint8_t *status_out, float *pt_predict,
                      float *pt_predict_un);
 
+/* Geometry validation, the consumer after the post-filter:
+ * the per-correspondence scoring loops of GyroAidedTracker::CheckHomography
+ * (src/gyro_aided_tracker.cpp:620-676) and ::CheckFundamental (:704-768).  The RANSAC fits in front
+ * of them (cv::findHomography / cv::findFundamentalMat, :596, :699) and H21.inv() (:597) are
+ * third-party and stay with the caller, who passes the fitted 3x3 matrices (row-major double, the
+ * layout of a CV_64F cv::Mat).  One launch scores both models (the reference runs them on two
+ * threads, :455-460); inlier flags and the float scores, accumulated in index order, are
+ * bit-identical to the reference loops.  pts1 / pts2: n x 2 float (mvKeysRefUn[i].pt, mvPtPredictUn[i]
+ * of the status-true features, :434-440).
+ *   pagk_geometry_scores_device: device pointers (d_scores: 2 floats, [0] = H, [1] = F),
+ *                                asynchronous on the context stream;
+ *   pagk_geometry_scores:        host buffers, synchronous. */
+int pagk_geometry_scores_device(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
+                                int32_t n, const float *d_pts1, const float *d_pts2, float sigma,
+                                uint8_t *d_inliers_H, uint8_t *d_inliers_F, float *d_scores);
+int pagk_geometry_scores(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21, int32_t n,
+                         const float *pts1, const float *pts2, float sigma, uint8_t *inliers_H,
+                         uint8_t *inliers_F, float *score_H, float *score_F);
+/* Model choice of GeometryValidation (:462-470): 1 = homography (RH = score_H / (score_F + score_H)
+ * > 0.45), 0 = fundamental. */
+int pagk_geometry_select(float score_H, float score_F);
+/* GyroAidedTracker::GeometryValidation (:429-480) around the fits: compacts the status-true
+ * correspondences (:434-440), does nothing unless more than 8 remain (:445), scores both models on the
+ * device, clears the status of the chosen model's outliers (:472-480).  status: n flags, updated in
+ * place; track_score (may be NULL) receives the chosen model's score.  Host buffers, synchronous.
+ * Returns cnt_inlier (>= 0; 0 when nothing was validated) or a negative error. */
+int pagk_geometry_validation(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
+                             int32_t n, const float *pt_ref_un, const float *pt_predict_un,
+                             uint8_t *status, float sigma, float *track_score);
+
 #ifdef __cplusplus
 }
 #endif

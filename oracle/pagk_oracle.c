@@ -767,3 +767,137 @@ int pagk_oracle_gyro_predict(const pagk_params *cam, int32_t width, int32_t heig
     }
     return n_predict;
 }
+
+/* ---- geometry validation: the scoring loops next to the path ------------------- */
+/* GyroAidedTracker::CheckHomography, src/gyro_aided_tracker.cpp:620-676.  The h's are double, the
+ * points float: products and sums run in double (usual arithmetic conversions), each `const float`
+ * initialiser narrows once. */
+int pagk_oracle_check_homography(const double *H21, const double *H12, int32_t n, const float *pts1,
+                                 const float *pts2, float sigma, uint8_t *inliers, float *score_out)
+{
+    if (n < 0 || !H21 || !H12 || !score_out || (n > 0 && (!pts1 || !pts2 || !inliers))) return PAGK_E_ARG;
+    const double h11 = H21[0], h12 = H21[1], h13 = H21[2], h21 = H21[3], h22 = H21[4], h23 = H21[5];
+    const double h31 = H21[6], h32 = H21[7], h33 = H21[8];
+    const double h11inv = H12[0], h12inv = H12[1], h13inv = H12[2], h21inv = H12[3], h22inv = H12[4];
+    const double h23inv = H12[5], h31inv = H12[6], h32inv = H12[7], h33inv = H12[8];
+    float score = 0;                                    /* :623 */
+    const float th = 5.99;                              /* :624 */
+    const float invSigmaSquare = 1.0 / (sigma * sigma); /* :625  float product, double divide, narrowed */
+    for (int i = 0; i < n; i++) {
+        int bIn = 1;
+        const float u1 = pts1[2 * i], v1 = pts1[2 * i + 1], u2 = pts2[2 * i], v2 = pts2[2 * i + 1];
+        const float w1in2inv = 1.0 / (h31 * u1 + h32 * v1 + h33); /* :641 */
+        const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
+        const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
+        const float squareDist2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2); /* :645 */
+        const float chiSquare2 = squareDist2 * invSigmaSquare;
+        if (chiSquare2 > th) /* :648  a NaN takes the else branch */
+            bIn = 0;
+        else
+            score += th - chiSquare2;
+        const float w2in1inv = 1.0 / (h31inv * u2 + h32inv * v2 + h33inv); /* :657 */
+        const float u2in1 = (h11inv * u2 + h12inv * v2 + h13inv) * w2in1inv;
+        const float v2in1 = (h21inv * u2 + h22inv * v2 + h23inv) * w2in1inv;
+        const float squareDist1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+        const float chiSquare1 = squareDist1 * invSigmaSquare;
+        if (chiSquare1 > th) /* :664 */
+            bIn = 0;
+        else
+            score += th - chiSquare1;
+        inliers[i] = (uint8_t)bIn; /* :671-676 */
+    }
+    *score_out = score;
+    return PAGK_OK;
+}
+
+/* GyroAidedTracker::CheckFundamental, src/gyro_aided_tracker.cpp:704-768. */
+int pagk_oracle_check_fundamental(const double *F21, int32_t n, const float *pts1, const float *pts2,
+                                  float sigma, uint8_t *inliers, float *score_out)
+{
+    if (n < 0 || !F21 || !score_out || (n > 0 && (!pts1 || !pts2 || !inliers))) return PAGK_E_ARG;
+    const double f11 = F21[0], f12 = F21[1], f13 = F21[2], f21 = F21[3], f22 = F21[4], f23 = F21[5];
+    const double f31 = F21[6], f32 = F21[7], f33 = F21[8];
+    float score = 0;
+    const float th = 3.84;      /* :707 */
+    const float thScore = 5.99; /* :708 */
+    const float invSigmaSquare = 1.0 / (sigma * sigma);
+    for (int i = 0; i < n; i++) {
+        int bIn = 1;
+        const float u1 = pts1[2 * i], v1 = pts1[2 * i + 1], u2 = pts2[2 * i], v2 = pts2[2 * i + 1];
+        const float a2 = f11 * u1 + f12 * v1 + f13; /* :725-727  l2 = F21 p1 */
+        const float b2 = f21 * u1 + f22 * v1 + f23;
+        const float c2 = f31 * u1 + f32 * v1 + f33;
+        const float num2 = a2 * u2 + b2 * v2 + c2; /* :730  float */
+        const float squareDist2 = num2 * num2 / (a2 * a2 + b2 * b2);
+        const float chiSquare2 = squareDist2 * invSigmaSquare;
+        if (chiSquare2 > th) /* :734 */
+            bIn = 0;
+        else
+            score += thScore - chiSquare2;
+        const float a1 = u2 * f11 + v2 * f21 + f31; /* :743-745  l1 = p2^T F21 */
+        const float b1 = u2 * f12 + v2 * f22 + f32;
+        const float c1 = u2 * f13 + v2 * f23 + f33;
+        const float num1 = a1 * u1 + b1 * v1 + c1;
+        const float squareDist1 = num1 * num1 / (a1 * a1 + b1 * b1);
+        const float chiSquare1 = squareDist1 * invSigmaSquare;
+        if (chiSquare1 > th) /* :752 */
+            bIn = 0;
+        else
+            score += thScore - chiSquare1;
+        inliers[i] = (uint8_t)bIn;
+    }
+    *score_out = score;
+    return PAGK_OK;
+}
+
+/* src/gyro_aided_tracker.cpp:459-469: `float RH = score_H / (score_F + score_H); if (RH > 0.45)` --
+ * the comparison promotes RH to double. */
+int pagk_oracle_geometry_select(float score_H, float score_F)
+{
+    float RH = score_H / (score_F + score_H);
+    return RH > 0.45 ? 1 : 0;
+}
+
+/* GyroAidedTracker::GeometryValidation, src/gyro_aided_tracker.cpp:429-478 (model fitting excluded:
+ * the fitted matrices come in as arguments). */
+int pagk_oracle_geometry_validation(const double *H21, const double *H12, const double *F21, int32_t n,
+                                    const float *pt_ref_un, const float *pt_predict_un, uint8_t *status,
+                                    float sigma, float *track_score)
+{
+    if (n < 0 || (n > 0 && (!pt_ref_un || !pt_predict_un || !status))) return PAGK_E_ARG;
+    int m = 0;
+    for (int i = 0; i < n; i++) m += status[i] ? 1 : 0; /* :434-440 */
+    if (track_score) *track_score = 0;
+    if (m <= 8) return 0; /* :445 */
+    int *idx = (int *)malloc(sizeof(int) * (size_t)m);
+    float *p1 = (float *)malloc(sizeof(float) * 2 * (size_t)m), *p2 = (float *)malloc(sizeof(float) * 2 * (size_t)m);
+    uint8_t *inH = (uint8_t *)malloc((size_t)m), *inF = (uint8_t *)malloc((size_t)m);
+    if (!idx || !p1 || !p2 || !inH || !inF) {
+        free(idx), free(p1), free(p2), free(inH), free(inF);
+        return PAGK_E_NOMEM;
+    }
+    for (int i = 0, k = 0; i < n; i++)
+        if (status[i]) {
+            idx[k] = i;
+            p1[2 * k] = pt_ref_un[2 * i], p1[2 * k + 1] = pt_ref_un[2 * i + 1];
+            p2[2 * k] = pt_predict_un[2 * i], p2[2 * k + 1] = pt_predict_un[2 * i + 1];
+            k++;
+        }
+    float sH = 0, sF = 0;
+    int rc = pagk_oracle_check_homography(H21, H12, m, p1, p2, sigma, inH, &sH);
+    if (rc == PAGK_OK) rc = pagk_oracle_check_fundamental(F21, m, p1, p2, sigma, inF, &sF);
+    int cnt_inlier = 0;
+    if (rc == PAGK_OK) {
+        const int useH = pagk_oracle_geometry_select(sH, sF);
+        const uint8_t *in = useH ? inH : inF;
+        if (track_score) *track_score = useH ? sH : sF;
+        for (int k = 0; k < m; k++) { /* :472-480 */
+            if (!in[k])
+                status[idx[k]] = 0;
+            else
+                cnt_inlier++;
+        }
+    }
+    free(idx), free(p1), free(p2), free(inH), free(inF);
+    return rc == PAGK_OK ? cnt_inlier : rc;
+}

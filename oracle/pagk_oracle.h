@@ -66,6 +66,29 @@ float pagk_oracle_inv_log_max_dist(float alpha, int32_t max_distance);
  * H: 16 doubles row-major (only the lower triangle is read); returns ||x||. */
 double pagk_oracle_llt_solve4(const double *H, const double *b, double *x);
 
+/* GyroAidedTracker::CheckHomography scoring loop (src/gyro_aided_tracker.cpp:620-676): symmetric
+ * transfer error of every correspondence under H21 (row-major 3x3 double, what cv::findHomography
+ * returned) and H12 = H21.inv() (the caller's cv::Mat::inv -- third-party arithmetic stays outside),
+ * chi-square test against 5.99, inlier flags, score accumulated in float in index order.
+ * pts1 / pts2: n x 2 float.  Returns PAGK_OK. */
+int pagk_oracle_check_homography(const double *H21, const double *H12, int32_t n, const float *pts1,
+                                 const float *pts2, float sigma, uint8_t *inliers, float *score);
+/* GyroAidedTracker::CheckFundamental scoring loop (src/gyro_aided_tracker.cpp:704-768): point to
+ * epipolar line distances under F21, test against 3.84, score against 5.99. */
+int pagk_oracle_check_fundamental(const double *F21, int32_t n, const float *pts1, const float *pts2,
+                                  float sigma, uint8_t *inliers, float *score);
+/* Model choice of GyroAidedTracker::GeometryValidation (src/gyro_aided_tracker.cpp:459-469):
+ * 1 = homography (RH > 0.45), 0 = fundamental. */
+int pagk_oracle_geometry_select(float score_H, float score_F);
+/* GyroAidedTracker::GeometryValidation bookkeeping (src/gyro_aided_tracker.cpp:433-478) around the two
+ * scoring loops: compacts the status-true correspondences, skips everything unless more than 8 remain,
+ * scores both models, keeps the chosen model's inliers.  status: n flags, updated in place.
+ * Returns cnt_inlier (0 when <= 8 correspondences: the reference then leaves mvStatus untouched and
+ * returns 0); track_score may be NULL. */
+int pagk_oracle_geometry_validation(const double *H21, const double *H12, const double *F21, int32_t n,
+                                    const float *pt_ref_un, const float *pt_predict_un, uint8_t *status,
+                                    float sigma, float *track_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,15 @@ def load():
         lib.pagk_oracle_inv_log_max_dist.argtypes = [C.c_float, i32]
         lib.pagk_oracle_llt_solve4.restype = C.c_double
         lib.pagk_oracle_llt_solve4.argtypes = [vp, vp, vp]
+        f32 = C.c_float
+        lib.pagk_oracle_check_homography.restype = C.c_int
+        lib.pagk_oracle_check_homography.argtypes = [vp, vp, i32, vp, vp, f32, vp, P(f32)]
+        lib.pagk_oracle_check_fundamental.restype = C.c_int
+        lib.pagk_oracle_check_fundamental.argtypes = [vp, i32, vp, vp, f32, vp, P(f32)]
+        lib.pagk_oracle_geometry_select.restype = C.c_int
+        lib.pagk_oracle_geometry_select.argtypes = [f32, f32]
+        lib.pagk_oracle_geometry_validation.restype = C.c_int
+        lib.pagk_oracle_geometry_validation.argtypes = [vp, vp, vp, i32, vp, vp, vp, f32, P(f32)]
         _lib = lib
     return _lib
 
@@ -127,3 +136,56 @@ def llt_solve4(H: np.ndarray, b: np.ndarray):
     x = np.zeros(4, np.float64)
     nrm = load().pagk_oracle_llt_solve4(H.ctypes.data, b.ctypes.data, x.ctypes.data)
     return x, nrm
+
+
+def _mat3(M):
+    M = np.ascontiguousarray(M, np.float64)
+    assert M.size == 9
+    return M
+
+
+def check_homography(H21, H12, pts1, pts2, sigma=1.0):
+    """CheckHomography scoring loop (reference src/gyro_aided_tracker.cpp:620-676) -> (inliers, score)."""
+    H21, H12 = _mat3(H21), _mat3(H12)
+    pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = pts1.shape[0]
+    inl = np.zeros(max(n, 1), np.uint8)
+    sc = C.c_float(0)
+    rc = load().pagk_oracle_check_homography(H21.ctypes.data, H12.ctypes.data, n, _p(pts1), _p(pts2), sigma,
+                                             _p(inl), C.byref(sc))
+    if rc < 0:
+        raise RuntimeError(f"pagk_oracle_check_homography: {rc}")
+    return inl[:n], np.float32(sc.value)
+
+
+def check_fundamental(F21, pts1, pts2, sigma=1.0):
+    """CheckFundamental scoring loop (reference src/gyro_aided_tracker.cpp:704-768) -> (inliers, score)."""
+    F21 = _mat3(F21)
+    pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = pts1.shape[0]
+    inl = np.zeros(max(n, 1), np.uint8)
+    sc = C.c_float(0)
+    rc = load().pagk_oracle_check_fundamental(F21.ctypes.data, n, _p(pts1), _p(pts2), sigma, _p(inl), C.byref(sc))
+    if rc < 0:
+        raise RuntimeError(f"pagk_oracle_check_fundamental: {rc}")
+    return inl[:n], np.float32(sc.value)
+
+
+def geometry_select(score_H, score_F) -> bool:
+    return bool(load().pagk_oracle_geometry_select(float(score_H), float(score_F)))
+
+
+def geometry_validation(H21, H12, F21, pt_ref_un, pt_predict_un, status, sigma=1.0):
+    """GeometryValidation bookkeeping (reference src/gyro_aided_tracker.cpp:429-480) -> (cnt, status, score)."""
+    H21, H12, F21 = _mat3(H21), _mat3(H12), _mat3(F21)
+    p1 = np.ascontiguousarray(pt_ref_un, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pt_predict_un, np.float32).reshape(-1, 2)
+    st = np.array(status, np.uint8, copy=True)
+    ts = C.c_float(0)
+    rc = load().pagk_oracle_geometry_validation(H21.ctypes.data, H12.ctypes.data, F21.ctypes.data, st.shape[0],
+                                                _p(p1), _p(p2), _p(st), sigma, C.byref(ts))
+    if rc < 0:
+        raise RuntimeError(f"pagk_oracle_geometry_validation: {rc}")
+    return rc, st, np.float32(ts.value)

@@ -99,10 +99,16 @@ def outputs_struct(d: dict) -> Outputs:
 
 
 def _ptr(a):
+    """Raw address of a numpy array or a torch tensor.  The C ABI takes dense row-major arrays: anything
+    else (a transposed view, a column-major array) is refused here rather than silently mis-read."""
     if a is None:
         return None
     if isinstance(a, np.ndarray):
+        if not a.flags.c_contiguous:
+            raise ValueError("array must be C-contiguous")
         return a.ctypes.data
+    if not a.is_contiguous():
+        raise ValueError("tensor must be contiguous")
     return a.data_ptr()
 
 
@@ -151,6 +157,15 @@ def declare(lib) -> None:
     lib.pagk_gyro_predict_device.argtypes = [vp, _P(Params), i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pagk_post_filter.restype = C.c_int
     lib.pagk_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    f32 = C.c_float
+    lib.pagk_geometry_scores_device.restype = C.c_int
+    lib.pagk_geometry_scores_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, vp]
+    lib.pagk_geometry_scores.restype = C.c_int
+    lib.pagk_geometry_scores.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, _P(f32), _P(f32)]
+    lib.pagk_geometry_select.restype = C.c_int
+    lib.pagk_geometry_select.argtypes = [f32, f32]
+    lib.pagk_geometry_validation.restype = C.c_int
+    lib.pagk_geometry_validation.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, f32, _P(f32)]
 
 
 EXPORTED_SYMBOLS = [
@@ -158,6 +173,7 @@ EXPORTED_SYMBOLS = [
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
     "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
+    "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
 ]
 
 
@@ -262,6 +278,53 @@ class Context:
                                                       _ptr(d_pt_predict), _ptr(d_status), _ptr(d_affine)),
                     "pagk_gyro_predict_device")
 
+    @staticmethod
+    def _mat3(M):
+        M = np.ascontiguousarray(M, np.float64)
+        if M.size != 9:
+            raise ValueError("expected a 3x3 matrix")
+        return M
+
+    def geometry_scores_device(self, H21, H12, F21, n: int, d_pts1, d_pts2, sigma: float, d_inl_H, d_inl_F,
+                               d_scores):
+        """CheckHomography / CheckFundamental scoring loops on device arrays (asynchronous)."""
+        H21, H12, F21 = self._mat3(H21), self._mat3(H12), self._mat3(F21)
+        self._check(self.lib.pagk_geometry_scores_device(self.h, H21.ctypes.data, H12.ctypes.data, F21.ctypes.data,
+                                                         n, _ptr(d_pts1), _ptr(d_pts2), sigma, _ptr(d_inl_H),
+                                                         _ptr(d_inl_F), _ptr(d_scores)),
+                    "pagk_geometry_scores_device")
+
+    def geometry_scores(self, H21, H12, F21, pts1, pts2, sigma: float = 1.0):
+        """Host buffers -> (inliers_H, inliers_F, score_H, score_F); reference
+        src/gyro_aided_tracker.cpp:620-676, 704-768."""
+        H21, H12, F21 = self._mat3(H21), self._mat3(H12), self._mat3(F21)
+        pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+        pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        n = pts1.shape[0]
+        if pts2.shape[0] != n:
+            raise ValueError("pts1 / pts2 differ in length")
+        inH, inF = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+        sH, sF = C.c_float(0), C.c_float(0)
+        self._check(self.lib.pagk_geometry_scores(self.h, H21.ctypes.data, H12.ctypes.data, F21.ctypes.data, n,
+                                                  _ptr(pts1), _ptr(pts2), sigma, _ptr(inH), _ptr(inF),
+                                                  C.byref(sH), C.byref(sF)), "pagk_geometry_scores")
+        return inH[:n], inF[:n], np.float32(sH.value), np.float32(sF.value)
+
+    def geometry_validation(self, H21, H12, F21, pt_ref_un, pt_predict_un, status, sigma: float = 1.0):
+        """GyroAidedTracker::GeometryValidation around externally fitted models
+        (src/gyro_aided_tracker.cpp:429-480) -> (cnt_inlier, status, track_score)."""
+        H21, H12, F21 = self._mat3(H21), self._mat3(H12), self._mat3(F21)
+        p1 = np.ascontiguousarray(pt_ref_un, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pt_predict_un, np.float32).reshape(-1, 2)
+        st = np.array(status, np.uint8, copy=True)
+        n = st.shape[0]
+        ts = C.c_float(0)
+        rc = self.lib.pagk_geometry_validation(self.h, H21.ctypes.data, H12.ctypes.data, F21.ctypes.data, n,
+                                               _ptr(p1), _ptr(p2), _ptr(st), sigma, C.byref(ts))
+        if rc < 0:
+            self._check(rc, "pagk_geometry_validation")
+        return rc, st, np.float32(ts.value)
+
     def sync(self):
         self._check(self.lib.pagk_sync(self.h), "pagk_sync")
 
@@ -289,3 +352,8 @@ def post_filter(half_patch: int, status_pm, pix_err, dist_pred, pt_pm, pt_pm_un)
     if rc < 0:
         raise PagkError(rc, "pagk_post_filter")
     return rc, status[:n], pp[:n], ppu[:n]
+
+
+def geometry_select(score_H: float, score_F: float) -> bool:
+    """True = homography chosen (RH > 0.45, reference src/gyro_aided_tracker.cpp:462-470)."""
+    return bool(load().pagk_geometry_select(float(score_H), float(score_F)))

@@ -298,3 +298,54 @@ int GyroAidedTracker::TrackFeatures()
     }
     return n_predict;
 }
+
+// ---- Step 2: geometry validation (reference :429-480) ----------------------------------------------
+namespace {
+GyroAidedTracker::ModelFitter &model_fitter()
+{
+    static GyroAidedTracker::ModelFitter f;
+    return f;
+}
+}  // namespace
+
+void GyroAidedTracker::SetModelFitter(ModelFitter fitter) { model_fitter() = std::move(fitter); }
+
+int GyroAidedTracker::GeometryValidation()
+{
+    if (!model_fitter())
+        throw std::runtime_error("GyroAidedTracker::GeometryValidation(): no model fitter installed "
+                                 "(cv::findHomography / cv::findFundamentalMat are the application's)");
+    std::vector<cv::Point2f> vPts1, vPts2;  // :433-440
+    for (size_t i = 0, iend = mvKeysRefUn.size(); i < iend; i++)
+        if (mvStatus[i]) {
+            vPts1.push_back(mvKeysRefUn[i].pt);
+            vPts2.push_back(mvPtPredictUn[i]);
+        }
+    double H21[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, H12[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, F21[9] = {0};
+    if (vPts1.size() > 8 && !model_fitter()(vPts1, vPts2, H21, H12, F21))  // :445, :596, :699
+        throw std::runtime_error("GyroAidedTracker::GeometryValidation(): model fit failed");
+    return GeometryValidation(H21, H12, F21);
+}
+
+int GyroAidedTracker::GeometryValidation(const double *H21, const double *H12, const double *F21, float sigma)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> p1(2 * (size_t)mN + 2), p2(2 * (size_t)mN + 2);
+    std::vector<cv::uchar> status(mN ? mN : 1);
+    for (int i = 0; i < mN; i++) {
+        p1[2 * i] = mvKeysRefUn[i].pt.x, p1[2 * i + 1] = mvKeysRefUn[i].pt.y;
+        p2[2 * i] = mvPtPredictUn[i].x, p2[2 * i + 1] = mvPtPredictUn[i].y;
+        status[i] = mvStatus[i];
+    }
+    float score = 0;
+    int cnt_inlier = pagk_geometry_validation(PatchMatch::Context(), H21, H12, F21, mN, p1.data(), p2.data(),
+                                              status.data(), sigma, &score);
+    if (cnt_inlier < 0)
+        throw std::runtime_error(std::string("pagk_geometry_validation failed: ") + pagk_strerror(cnt_inlier));
+    for (int i = 0; i < mN; i++) mvStatus[i] = status[i];  // :472-476  outliers marked
+    mTrackScore = score;
+    mTimeCostGeometryValidation = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+    mTImeCostTotalFeatureTrack =
+        mTimeCostGyroPredict + mTimeCostOptFlow + mTimeCostOptFlowResultFilterOut + mTimeCostGeometryValidation;  // :483
+    return cnt_inlier;
+}

@@ -1,9 +1,11 @@
 // gyro_aided_tracker.h -- the hot-path side of the reference's GyroAidedTracker
 // (include/gyro_aided_tracker.h:47-260): data constructor, TrackFeatures() type dispatch,
 // GyroPredictFeatures(), GyroPredictFeaturesAndOpticalFlowRefined() and the public result vectors
-// PatchMatch reads and writes.  Geometry validation, the unused matchers, display and logging are out
-// of scope and are not declared.
+// PatchMatch reads and writes, and GeometryValidation() around externally fitted models (the RANSAC fits
+// are cv::findHomography / cv::findFundamentalMat: third-party, supplied by the application).  The unused
+// matchers, display and logging are out of scope and are not declared.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -58,6 +60,18 @@ public:
 
     int GyroPredictFeatures();
     int GyroPredictFeaturesAndOpticalFlowRefined();
+
+    // Step 2 of the tracker, reference include/gyro_aided_tracker.h:134 / src/gyro_aided_tracker.cpp:429-480.
+    // The reference fits H21 and F21 inside CheckHomography / CheckFundamental with OpenCV's RANSAC
+    // (:596, :699) and inverts H21 with cv::Mat::inv (:597); here the application supplies those three
+    // 3x3 row-major double matrices -- through a fitter installed once, or per call -- and the scoring
+    // loops, the model choice and the outlier marking run behind pagk_geometry_validation.
+    using ModelFitter = std::function<bool(const std::vector<cv::Point2f> &vPts1, const std::vector<cv::Point2f> &vPts2,
+                                           double H21[9], double H12[9], double F21[9])>;
+    static void SetModelFitter(ModelFitter fitter);
+    int GeometryValidation();  // reference signature; needs a fitter (throws std::runtime_error without one)
+    int GeometryValidation(const double *H21, const double *H12, const double *F21, float sigma = 1.0f);
+    float mTrackScore = 0;  // `track_score` of the reference's log line (:447, :465-470)
     void IntegrateGyroMeasurements();
     cv::Mat IntegrateOneGyroMeasurement(cv::Point3f &gyro, double dt);
     void GyroPredictOnePixel(cv::Point2f &pt_ref, cv::Point2f &pt_predict, cv::Point2f &pt_predict_distort,
@@ -85,7 +99,8 @@ public:  // data members keep the reference's names (include/gyro_aided_tracker.
     std::vector<float> mvNccAfterPatchMatched;
     std::vector<cv::Point2f> mvFlowsPredictUn;
 
-    float mTimeCostGyroPredict = 0, mTimeCostOptFlow = 0, mTimeCostOptFlowResultFilterOut = 0;
+    float mTimeCostGyroPredict = 0, mTimeCostOptFlow = 0, mTimeCostOptFlowResultFilterOut = 0,
+          mTimeCostGeometryValidation = 0, mTImeCostTotalFeatureTrack = 0;
 
     cv::Mat mRbc, mRcl;
     float mr11, mr12, mr13, mr21, mr22, mr23, mr31, mr32, mr33;

@@ -86,5 +86,42 @@ int pagk_tracker_track_features(const unsigned char *img_ref, const unsigned cha
     }
 }
 
+// GyroAidedTracker::GeometryValidation (reference :429-480) on a tracker whose state is given by the
+// arrays: keys_ref_un / pt_predict_un (n x 2), status (n, updated in place).  H21, H12, F21: the fitted
+// models, 3x3 row-major double.  Returns cnt_inlier or -100 on an exception; *track_score as the reference logs it.
+int pagk_tracker_geometry_validation(int n, const float *keys_ref_un, const float *pt_predict_un, unsigned char *status,
+                                     const double *H21, const double *H12, const double *F21, float *track_score)
+{
+    try {
+        static unsigned char px = 0;
+        cv::Mat img(1, 1, cv::CV_8UC1, &px, 1);
+        std::vector<cv::KeyPoint> keys(n), none;
+        for (int i = 0; i < n; i++) keys[i].pt = cv::Point2f(keys_ref_un[2 * i], keys_ref_un[2 * i + 1]);
+        cv::Mat Km = cv::Mat::eye(3, 3, cv::CV_32F), Dm(1, 4, cv::CV_32F), table;
+        for (int k = 0; k < 4; k++) Dm.at<float>(k) = 0;
+        std::vector<IMU::Point> vimu;
+        GyroAidedTracker trk(0, 0, img, img, keys, none, keys, none, vimu, cv::Point3f(0, 0, 0), Km, Dm, table);
+        for (int i = 0; i < n; i++) {
+            trk.mvStatus[i] = status[i];
+            trk.mvPtPredictUn[i] = cv::Point2f(pt_predict_un[2 * i], pt_predict_un[2 * i + 1]);
+        }
+        // through the installed-fitter form, the way an application with OpenCV would wire it
+        GyroAidedTracker::SetModelFitter([&](const std::vector<cv::Point2f> &, const std::vector<cv::Point2f> &,
+                                             double h21[9], double h12[9], double f21[9]) {
+            for (int k = 0; k < 9; k++) h21[k] = H21[k], h12[k] = H12[k], f21[k] = F21[k];
+            return true;
+        });
+        int ret = trk.GeometryValidation();
+        GyroAidedTracker::SetModelFitter(nullptr);
+        for (int i = 0; i < n; i++) status[i] = trk.mvStatus[i];
+        if (track_score) *track_score = trk.mTrackScore;
+        return ret;
+    } catch (const std::exception &e) {
+        GyroAidedTracker::SetModelFitter(nullptr);
+        g_err = e.what();
+        return -100;
+    }
+}
+
 void pagk_tracker_release(void) { PatchMatch::ReleaseContext(); }
 }

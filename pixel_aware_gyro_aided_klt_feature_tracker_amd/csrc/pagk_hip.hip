@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/pagk.h"
 #include "pagk_kernels.h"
@@ -43,6 +44,7 @@ struct pagk_ctx {
     hipStream_t stream = nullptr;
     FrameSlot slots[kSlots];
     FeatBuf feat;
+    FeatBuf score;  // scratch of the host-buffer geometry scoring path
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
@@ -506,6 +508,7 @@ void pagk_destroy(pagk_ctx *ctx)
     for (auto &s : ctx->slots)
         if (s.block) (void)hipFree(s.block);
     if (ctx->feat.block) (void)hipFree(ctx->feat.block);
+    if (ctx->score.block) (void)hipFree(ctx->score.block);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
         if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);
@@ -773,6 +776,108 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm, co
         kept++;
     }
     return kept;
+}
+
+
+// ---- geometry validation scoring ----------------------------------
+int pagk_geometry_scores_device(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
+                                int32_t n, const float *d_pts1, const float *d_pts2, float sigma,
+                                uint8_t *d_inliers_H, uint8_t *d_inliers_F, float *d_scores)
+{
+    if (!ctx || !H21 || !H12 || !F21 || n < 0 || !d_scores) return PAGK_E_ARG;
+    if (n > 0 && (!d_pts1 || !d_pts2 || !d_inliers_H || !d_inliers_F)) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ScoreArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 9; k++) a.H21[k] = H21[k], a.H12[k] = H12[k], a.F21[k] = F21[k];
+    a.pts1 = d_pts1, a.pts2 = d_pts2, a.n = n, a.sigma = sigma;
+    a.inl_H = d_inliers_H, a.inl_F = d_inliers_F, a.scores = d_scores;
+    hipLaunchKernelGGL(k_geometry_scores, dim3(2), dim3(256), 0, ctx->stream, a);  // n == 0: scores = 0
+    HIPCHK(ctx, hipGetLastError());
+    return PAGK_OK;
+}
+
+int pagk_geometry_scores(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21, int32_t n,
+                         const float *pts1, const float *pts2, float sigma, uint8_t *inliers_H,
+                         uint8_t *inliers_F, float *score_H, float *score_F)
+{
+    if (!ctx || !H21 || !H12 || !F21 || n < 0 || !score_H || !score_F) return PAGK_E_ARG;
+    if (n > 0 && (!pts1 || !pts2 || !inliers_H || !inliers_F)) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)(n < 1 ? 1 : n);
+    const size_t o_p2 = align_up(nn * 8, 256), o_h = o_p2 + align_up(nn * 8, 256), o_f = o_h + align_up(nn, 256);
+    const size_t o_s = o_f + align_up(nn, 256), total = o_s + 256;
+    if (total > ctx->score.bytes) {
+        if (ctx->score.block) HIPCHK(ctx, hipFree(ctx->score.block));
+        ctx->score.block = nullptr;
+        ctx->score.bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->score.block, total));
+        ctx->score.bytes = total;
+    }
+    uint8_t *b = static_cast<uint8_t *>(ctx->score.block);
+    float *d_p1 = reinterpret_cast<float *>(b), *d_p2 = reinterpret_cast<float *>(b + o_p2);
+    float *d_s = reinterpret_cast<float *>(b + o_s);
+    if (n > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_p2, pts2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = pagk_geometry_scores_device(ctx, H21, H12, F21, n, d_p1, d_p2, sigma, b + o_h, b + o_f, d_s);
+    if (rc) return rc;
+    float sc[2];
+    if (n > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(inliers_H, b + o_h, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(inliers_F, b + o_f, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(sc, d_s, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *score_H = sc[0];
+    *score_F = sc[1];
+    return PAGK_OK;
+}
+
+// src/gyro_aided_tracker.cpp:462-465: `float RH = ...; if (RH > 0.45)` compares in double.
+int pagk_geometry_select(float score_H, float score_F)
+{
+    const float RH = score_H / (score_F + score_H);
+    return RH > 0.45 ? 1 : 0;
+}
+
+int pagk_geometry_validation(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
+                             int32_t n, const float *pt_ref_un, const float *pt_predict_un,
+                             uint8_t *status, float sigma, float *track_score)
+{
+    if (!ctx || !H21 || !H12 || !F21 || n < 0) return PAGK_E_ARG;
+    if (n > 0 && (!pt_ref_un || !pt_predict_un || !status)) return PAGK_E_ARG;
+    if (track_score) *track_score = 0;  // :447
+    try {
+    std::vector<int> idx;               // :433-440
+    std::vector<float> p1, p2;
+    for (int i = 0; i < n; i++)
+        if (status[i]) {
+            idx.push_back(i);
+            p1.push_back(pt_ref_un[2 * i]), p1.push_back(pt_ref_un[2 * i + 1]);
+            p2.push_back(pt_predict_un[2 * i]), p2.push_back(pt_predict_un[2 * i + 1]);
+        }
+    const int m = (int)idx.size();
+    if (m <= 8) return 0;  // :445
+    std::vector<uint8_t> inH((size_t)m), inF((size_t)m);
+    float sH = 0, sF = 0;
+    int rc = pagk_geometry_scores(ctx, H21, H12, F21, m, p1.data(), p2.data(), sigma, inH.data(), inF.data(), &sH, &sF);
+    if (rc) return rc;
+    const bool useH = pagk_geometry_select(sH, sF) != 0;  // :462-470
+    const std::vector<uint8_t> &in = useH ? inH : inF;
+    if (track_score) *track_score = useH ? sH : sF;
+    int cnt_inlier = 0;
+    for (int k = 0; k < m; k++) {  // :472-480
+        if (!in[k])
+            status[idx[k]] = 0;
+        else
+            cnt_inlier++;
+    }
+    return cnt_inlier;
+    } catch (const std::bad_alloc &) {  // nothing crosses the C ABI
+        return PAGK_E_NOMEM;
+    }
 }
 
 }  // extern "C"

@@ -777,3 +777,4 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
 }  // namespace pagk
 
 #include "pagk_wave_kernel.h"
+#include "pagk_score_kernel.h"

@@ -24,6 +24,8 @@ def load():
         lib.pagk_tracker_track_features.restype = C.c_int
         lib.pagk_tracker_track_features.argtypes = [vp, vp, i, i, C.c_long, i, vp, vp, vp, i, i, i, i, vp, vp, i,
                                                     C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.pagk_tracker_geometry_validation.restype = C.c_int
+        lib.pagk_tracker_geometry_validation.argtypes = [i, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
         lib.pagk_tracker_last_error.restype = C.c_char_p
         lib.pagk_tracker_release.restype = None
         _lib = lib
@@ -56,3 +58,19 @@ def track_features(img_ref, img_cur, keys_ref, K, dist, *, type=4, half_patch=5,
     if ret == -100:
         raise RuntimeError("GyroAidedTracker: " + lib.pagk_tracker_last_error().decode())
     return ret, {k: v[:n] for k, v in out.items()}
+
+
+def geometry_validation(keys_ref_un, pt_predict_un, status, H21, H12, F21):
+    """GyroAidedTracker::GeometryValidation() with an installed model fitter (reference
+    src/gyro_aided_tracker.cpp:429-480) -> (cnt_inlier, status, track_score)."""
+    lib = load()
+    k = np.ascontiguousarray(keys_ref_un, np.float32).reshape(-1, 2)
+    q = np.ascontiguousarray(pt_predict_un, np.float32).reshape(-1, 2)
+    st = np.array(status, np.uint8, copy=True)
+    H21, H12, F21 = (np.ascontiguousarray(M, np.float64) for M in (H21, H12, F21))
+    ts = C.c_float(0)
+    ret = lib.pagk_tracker_geometry_validation(int(st.shape[0]), k.ctypes.data, q.ctypes.data, st.ctypes.data,
+                                               H21.ctypes.data, H12.ctypes.data, F21.ctypes.data, C.byref(ts))
+    if ret == -100:
+        raise RuntimeError("GyroAidedTracker: " + lib.pagk_tracker_last_error().decode())
+    return ret, st, np.float32(ts.value)

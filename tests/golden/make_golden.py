@@ -85,5 +85,34 @@ def main():
         print(f"{name}: n={w.n} ok={int(out['status'][:w.n].sum())} mean iters {out['iters'][:w.n].mean():.2f}")
 
 
+def main_geometry():
+    """Geometry validation scoring (reference src/gyro_aided_tracker.cpp:429-480, 589-768): oracle outputs on
+    seeded two-view scenes; the fitted models are numpy stand-ins (tests/util.make_geometry_case)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from util import GEOM_DIR, make_geometry_case
+    os.makedirs(GEOM_DIR, exist_ok=True)
+    cases = {
+        "general_300": make_geometry_case(0x6E0A0001, 300),
+        "planar_300": make_geometry_case(0x6E0A0002, 300, planar=True),
+        "clean_64": make_geometry_case(0x6E0A0003, 64, outlier_fraction=0.0, noise_px=0.1),
+        "chunked_4500": make_geometry_case(0x6E0A0004, 4500, outlier_fraction=0.3),
+        "few_11": make_geometry_case(0x6E0A0005, 11),   # 9 status-true correspondences: validated (> 8, :445)
+        "few_10": make_geometry_case(0x6E0A0006, 10),  # 8 status-true correspondences: left untouched
+    }
+    for name, g in cases.items():
+        inH, sH = orc.check_homography(g["H21"], g["H12"], g["pts1"], g["pts2"], float(g["sigma"]))
+        inF, sF = orc.check_fundamental(g["F21"], g["pts1"], g["pts2"], float(g["sigma"]))
+        n = g["pts1"].shape[0]
+        status = np.ones(n, np.uint8)
+        status[::7] = 0
+        cnt, st, ts = orc.geometry_validation(g["H21"], g["H12"], g["F21"], g["pts1"], g["pts2"], status, float(g["sigma"]))
+        np.savez_compressed(os.path.join(GEOM_DIR, name + ".npz"), **g, status_in=status, out_inl_H=inH, out_inl_F=inF,
+                            out_score_H=sH, out_score_F=sF, out_cnt=np.int32(cnt), out_status=st, out_track_score=ts)
+        print(f"geometry/{name}: n={n} inliers H {int(inH.sum())} F {int(inF.sum())} scores {sH:.3f} {sF:.3f} "
+              f"choose {'H' if orc.geometry_select(sH, sF) else 'F'} validated {cnt}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--geometry-only" not in sys.argv:
+        main()
+    main_geometry()

@@ -161,3 +161,20 @@ def test_cpp_demo_loop_over_a_sequence(built, tmp_path):
     surv, _, cs = lines[-1].split()[1], lines[-1].split()[2], float(lines[-1].split()[3])
     assert int(surv) == keys.shape[0] and keys.shape[0] > 0.7 * NK
     assert abs(cs - checksum) <= 1e-3 * max(1.0, abs(checksum)) * 1e-3
+
+
+@pytest.mark.gpu
+def test_shell_geometry_validation(built):
+    # GyroAidedTracker::GeometryValidation() with an installed model fitter (reference :429-480)
+    from util import make_geometry_case
+    g = make_geometry_case(0x6E0B, 700, outlier_fraction=0.2)
+    rng = np.random.default_rng(9)
+    st = (rng.random(700) < 0.85).astype(np.uint8)
+    cnt, out, ts = host_api.geometry_validation(g["pts1"], g["pts2"], st, g["H21"], g["H12"], g["F21"])
+    rcnt, rout, rts = orc.geometry_validation(g["H21"], g["H12"], g["F21"], g["pts1"], g["pts2"], st)
+    assert cnt == rcnt and np.array_equal(out, rout) and ts.tobytes() == rts.tobytes()
+    few = np.zeros(700, np.uint8)
+    few[10:18] = 1   # 8 correspondences: the reference validates nothing and returns 0 (:445)
+    cnt, out, ts = host_api.geometry_validation(g["pts1"], g["pts2"], few, g["H21"], g["H12"], g["F21"])
+    assert cnt == 0 and np.array_equal(out, few)
+    host_api.load().pagk_tracker_release()

@@ -49,3 +49,48 @@ def assert_parity(got, ref, n, status_in=None, exact=True, what=""):
             if k in got and k in ref and got[k] is not None and ref[k] is not None:
                 a, b = got[k][:n], ref[k][:n]
                 assert np.array_equal(a, b, equal_nan=True), f"{what}: {k} not bit-identical (max diff {np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))})"
+
+
+# ---- geometry validation cases ---------------------------------------
+GEOM_DIR = os.path.join(GOLDEN_DIR, "geometry")
+
+
+def geometry_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GEOM_DIR, "*.npz")))
+
+
+def load_geometry(name):
+    z = np.load(os.path.join(GEOM_DIR, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def make_geometry_case(seed, n, outlier_fraction=0.1, noise_px=0.4, planar=False, translation=(0.05, -0.02, 0.01)):
+    """Correspondences of a seeded two-view scene plus stand-ins for the models RANSAC would fit:
+    H21 = K R K^-1 (or the plane-induced homography when `planar`), F21 = K^-T [t]x R K^-1 scaled to
+    f33 = 1 like cv::findFundamentalMat's output.  Pure numpy (float64), inputs only: the expected
+    outputs always come from the oracle."""
+    rng = np.random.default_rng(seed)
+    cam = synth.EUROC
+    K = np.array([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], np.float64)
+    R = synth.rodrigues(np.array([0.01, -0.02, 0.03]))
+    t = np.asarray(translation, np.float64)
+    uv1 = np.c_[rng.uniform(20, 732, n), rng.uniform(20, 460, n)]
+    depth = np.full(n, 4.0) if planar else rng.uniform(2.0, 12.0, n)
+    X1 = (np.linalg.inv(K) @ np.c_[uv1, np.ones(n)].T) * depth
+    X2 = R @ X1 + t[:, None]
+    uv2 = (K @ X2).T
+    uv2 = uv2[:, :2] / uv2[:, 2:]
+    uv2 += rng.normal(0, noise_px, uv2.shape)
+    bad = rng.random(n) < outlier_fraction
+    uv2[bad] += rng.uniform(-30, 30, (int(bad.sum()), 2))
+    if planar:   # plane z = 4 in camera 1: H = K (R + t n^T / d) K^-1
+        H21 = K @ (R + np.outer(t, [0, 0, 1]) / 4.0) @ np.linalg.inv(K)
+    else:
+        H21 = K @ R @ np.linalg.inv(K)
+    H21 = H21 / H21[2, 2]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F21 = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    F21 = F21 / F21[2, 2]
+    c = np.ascontiguousarray   # (K @ X).T arithmetic leaves column-major arrays behind
+    return dict(H21=c(H21), H12=c(np.linalg.inv(H21)), F21=c(F21), pts1=c(uv1, np.float32), pts2=c(uv2, np.float32),
+                sigma=np.float32(1.0))
