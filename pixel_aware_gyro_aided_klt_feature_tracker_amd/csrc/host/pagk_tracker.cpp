@@ -7,6 +7,7 @@
 
 #include "gyro_aided_tracker.h"
 #include "patch_match.h"
+#include "sequence_io.h"
 
 static thread_local std::string g_err;
 
@@ -121,6 +122,73 @@ int pagk_tracker_geometry_validation(int n, const float *keys_ref_un, const floa
         g_err = e.what();
         return -100;
     }
+}
+
+// ---- sequence formats (sequence_io.h), flat C views for tests and other languages ------------------
+// Each returns the number of records (written up to `cap`), or -1 if the file cannot be opened.
+int pagk_seq_load_keypoints(const char *path, float *xy /*cap x 2*/, int cap)
+{
+    std::vector<cv::Point2f> pts;
+    if (!pagk_seq::LoadDetectedKeypoints(path, pts)) return -1;
+    for (int i = 0; i < (int)pts.size() && i < cap; i++) xy[2 * i] = pts[i].x, xy[2 * i + 1] = pts[i].y;
+    return (int)pts.size();
+}
+// times: cap doubles; names: cap x name_len chars, NUL-terminated
+int pagk_seq_load_correspondences(const char *path, double *times, char *names, int name_len, int cap)
+{
+    std::vector<std::pair<double, std::string>> v;
+    if (!pagk_seq::LoadCorrespondences(path, v)) return -1;
+    for (int i = 0; i < (int)v.size() && i < cap; i++) {
+        times[i] = v[i].first;
+        std::strncpy(names + (size_t)i * name_len, v[i].second.c_str(), (size_t)name_len - 1);
+        names[(size_t)i * name_len + name_len - 1] = 0;
+    }
+    return (int)v.size();
+}
+int pagk_seq_find_time(const double *times, int n, double t)
+{
+    std::vector<std::pair<double, std::string>> v((size_t)n);
+    for (int i = 0; i < n; i++) v[i].first = times[i];
+    return pagk_seq::FindTimeCorrespondenIndex(v, t);
+}
+int pagk_seq_parse_image_line(const char *line, double *time_s)
+{
+    return pagk_seq::ParseImageListLine(line, *time_s) ? 1 : 0;
+}
+// out: cap x 7 doubles (ax ay az wx wy wz t), the layout pagk_tracker_track_features takes
+int pagk_seq_load_imu(const char *path, double *out, int cap)
+{
+    std::vector<IMU::Point> v;
+    if (!pagk_seq::LoadImu(path, v)) return -1;
+    for (int i = 0; i < (int)v.size() && i < cap; i++) {
+        double *o = out + 7 * (size_t)i;
+        o[0] = v[i].a.x, o[1] = v[i].a.y, o[2] = v[i].a.z, o[3] = v[i].w.x, o[4] = v[i].w.y, o[5] = v[i].w.z, o[6] = v[i].t;
+    }
+    return (int)v.size();
+}
+// The demo's IMU window over a frame-time list: counts[k] = samples handed to the tracker for the pair
+// (times[k-1], times[k]), first[k] = index of the first of them in the IMU file (-1 if none).
+int pagk_seq_imu_windows(const char *imu_path, const double *frame_times, int n_frames, int *first, int *counts)
+{
+    std::vector<IMU::Point> all;
+    if (!pagk_seq::LoadImu(imu_path, all)) return -1;
+    std::vector<double> stamps;
+    for (auto &p : all) stamps.push_back(p.t);
+    pagk_seq::ImuWindow win(all);
+    double t_prev = 0;
+    for (int k = 0; k < n_frames; k++) {
+        std::vector<IMU::Point> w = win.Next(t_prev, frame_times[k]);
+        counts[k] = (int)w.size();
+        first[k] = -1;
+        if (!w.empty())
+            for (size_t j = 0; j < stamps.size(); j++)
+                if (stamps[j] == w[0].t) {
+                    first[k] = (int)j;
+                    break;
+                }
+        t_prev = frame_times[k];
+    }
+    return (int)all.size();
 }
 
 void pagk_tracker_release(void) { PatchMatch::ReleaseContext(); }

@@ -26,6 +26,18 @@ def load():
                                                     C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.pagk_tracker_geometry_validation.restype = C.c_int
         lib.pagk_tracker_geometry_validation.argtypes = [i, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+        lib.pagk_seq_load_keypoints.restype = C.c_int
+        lib.pagk_seq_load_keypoints.argtypes = [C.c_char_p, vp, i]
+        lib.pagk_seq_load_correspondences.restype = C.c_int
+        lib.pagk_seq_load_correspondences.argtypes = [C.c_char_p, vp, vp, i, i]
+        lib.pagk_seq_find_time.restype = C.c_int
+        lib.pagk_seq_find_time.argtypes = [vp, i, C.c_double]
+        lib.pagk_seq_parse_image_line.restype = C.c_int
+        lib.pagk_seq_parse_image_line.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        lib.pagk_seq_load_imu.restype = C.c_int
+        lib.pagk_seq_load_imu.argtypes = [C.c_char_p, vp, i]
+        lib.pagk_seq_imu_windows.restype = C.c_int
+        lib.pagk_seq_imu_windows.argtypes = [C.c_char_p, vp, i, vp, vp]
         lib.pagk_tracker_last_error.restype = C.c_char_p
         lib.pagk_tracker_release.restype = None
         _lib = lib
@@ -74,3 +86,63 @@ def geometry_validation(keys_ref_un, pt_predict_un, status, H21, H12, F21):
     if ret == -100:
         raise RuntimeError("GyroAidedTracker: " + lib.pagk_tracker_last_error().decode())
     return ret, st, np.float32(ts.value)
+
+
+# ---- sequence formats of the reference's demo (csrc/host/sequence_io.h) ----
+def load_keypoints(path: str) -> np.ndarray:
+    """SuperPoint keypoint list "idx, x, y" (reference src/frame.cpp:222-240) -> n x 2 float32."""
+    lib = load()
+    n = lib.pagk_seq_load_keypoints(path.encode(), None, 0)
+    if n < 0:
+        raise FileNotFoundError(path)
+    xy = np.zeros((max(n, 1), 2), np.float32)
+    lib.pagk_seq_load_keypoints(path.encode(), xy.ctypes.data, n)
+    return xy[:n]
+
+
+def load_correspondences(path: str):
+    """corresponds.txt "<t_seconds>, <stamp>" (reference Examples/Demo/RealSenseD435i.cpp:167-182)."""
+    lib = load()
+    n = lib.pagk_seq_load_correspondences(path.encode(), None, None, 64, 0)
+    if n < 0:
+        raise FileNotFoundError(path)
+    times = np.zeros(max(n, 1), np.float64)
+    names = C.create_string_buffer(64 * max(n, 1))
+    lib.pagk_seq_load_correspondences(path.encode(), times.ctypes.data, C.addressof(names), 64, n)
+    raw = names.raw
+    return times[:n], [raw[64 * k:64 * k + 64].split(b"\0", 1)[0].decode() for k in range(n)]
+
+
+def find_time(times: np.ndarray, t: float) -> int:
+    """findTimeCorrespondenIndex (reference include/common.h:105-114)."""
+    times = np.ascontiguousarray(times, np.float64)
+    return load().pagk_seq_find_time(times.ctypes.data, int(times.shape[0]), float(t))
+
+
+def parse_image_line(line: str):
+    """One line of image_file_list.txt -> time in seconds, or None (reference RealSenseD435i.cpp:89-94)."""
+    t = C.c_double(0)
+    return t.value if load().pagk_seq_parse_image_line(line.encode(), C.byref(t)) else None
+
+
+def load_imu(path: str) -> np.ndarray:
+    """imu.txt "<stamp_ns> ax ay az wx wy wz" (reference RealSenseD435i.cpp:102-141) -> n x 7 (ax..wz, t)."""
+    lib = load()
+    n = lib.pagk_seq_load_imu(path.encode(), None, 0)
+    if n < 0:
+        raise FileNotFoundError(path)
+    out = np.zeros((max(n, 1), 7), np.float64)
+    lib.pagk_seq_load_imu(path.encode(), out.ctypes.data, n)
+    return out[:n]
+
+
+def imu_windows(imu_path: str, frame_times):
+    """The demo's streaming IMU window per frame pair (reference RealSenseD435i.cpp:196-218) ->
+    (first_index, count) per frame."""
+    ft = np.ascontiguousarray(frame_times, np.float64)
+    first = np.zeros(max(len(ft), 1), np.int32)
+    counts = np.zeros(max(len(ft), 1), np.int32)
+    n = load().pagk_seq_imu_windows(imu_path.encode(), ft.ctypes.data, len(ft), first.ctypes.data, counts.ctypes.data)
+    if n < 0:
+        raise FileNotFoundError(imu_path)
+    return first[:len(ft)], counts[:len(ft)]
