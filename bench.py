@@ -171,18 +171,15 @@ def main() -> int:
         #     tail of each other's slowest features.  Reported beside `value`, not as `value`.
         C = max(1, args.cameras)
         cams = []
-        for c in range(C):
-            st = torch.cuda.Stream()
-            with torch.cuda.stream(st):
-                r2 = runtime.ResidentTracker(p, device=local_rank)
-                r2.load_pair(w.img_ref, w.img_cur)
-                r2.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
-            cams.append((st, r2))
-        def cam_steps(k):
+        for c in range(C):   # every tracker owns its pair of HIP streams
+            r2 = runtime.ResidentTracker(p, device=local_rank)
+            r2.load_pair(w.img_ref, w.img_cur)
+            r2.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+            cams.append(r2)
+        def cam_steps(k, **kw):
             for _ in range(k):
-                for st, r2 in cams:
-                    with torch.cuda.stream(st):
-                        r2.step()
+                for r2 in cams:
+                    r2.step(**kw)
         cam_steps(5)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -192,8 +189,22 @@ def main() -> int:
         tc = time.perf_counter() - t1
         extras["multi_camera"] = {"value": n_active_total * C * ksteps / tc, "unit": "features/s", "cameras": C,
                                   "steps_per_camera": ksteps,
-                                  "what": f"{C} independent streams of the same workload in flight on one GPU"}
-        for _, r2 in cams:
+                                  "what": f"{C} independent cameras (one hipGraph replay per camera and frame) in "
+                                          "flight on one GPU"}
+        # (c) how the step's two launches reach the GPU (runtime.ResidentTracker.step modes), one camera:
+        #     `value` uses "graph" (one hipGraphLaunch replaying [pyramid -> PatchMatch])
+        modes = {}
+        for m in ("graph", "serial", "streams"):
+            for _ in range(5):
+                cams[0].step(mode=m)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(ksteps):
+                cams[0].step(mode=m)
+            torch.cuda.synchronize()
+            modes[m] = (time.perf_counter() - t1) / ksteps * 1e3
+        extras["step_modes_ms"] = modes
+        for r2 in cams:
             r2.close()
 
     if rank == 0:
@@ -214,8 +225,8 @@ def main() -> int:
                                    "(synthetic stand-in for BASELINE configs[1])",
                        "features_total": n_total, "features_active": n_active_total,
                        "sharding": f"contiguous feature blocks x{world} + all-gather" if world > 1 else "none",
-                       "step": "pyramid(current frame; built on a side stream while the previous pair tracks) + "
-                               "PatchMatch(all features)" + (" + all-gather" if world > 1 else "")},
+                       "step": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch"
+                               + (" + all-gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": (f"profiles/{traffic_tag}/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB "

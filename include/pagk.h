@@ -186,6 +186,20 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
                      const float *pt_pm_un, uint8_t *status_out, float *pt_predict,
                      float *pt_predict_un);
 
+/* hipGraph capture of the per-frame work (BASELINE configs[4], "hipGraph-captured iterate").  A camera
+ * stream issues the same launches on the same device pointers every frame; between pagk_graph_begin and
+ * pagk_graph_end the *_device entry points (pagk_frame_set_device, pagk_gyro_predict_device,
+ * pagk_track_device, pagk_geometry_scores_device) are recorded on the context stream instead of executed,
+ * pagk_graph_launch replays them with one hipGraphLaunch.  Rules: run the same calls once before capturing
+ * (nothing may allocate during capture); host-buffer and synchronising entry points return PAGK_E_ARG while
+ * capturing; the context stream must not be the legacy default stream; the kernel timers
+ * (pagk_last_kernel_ms) do not see replays.  Up to 8 graphs per context.  The reference has no counterpart:
+ * its per-frame loop is Examples/Demo/RealSenseD435i.cpp:199-321. */
+int pagk_graph_begin(pagk_ctx *ctx);
+int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id);
+int pagk_graph_launch(pagk_ctx *ctx, int32_t graph_id);
+int pagk_graph_destroy(pagk_ctx *ctx, int32_t graph_id);
+
 /* Geometry validation, the consumer after the post-filter:
  * the per-correspondence scoring loops of GyroAidedTracker::CheckHomography
  * (src/gyro_aided_tracker.cpp:620-676) and ::CheckFundamental (:704-768).  The RANSAC fits in front

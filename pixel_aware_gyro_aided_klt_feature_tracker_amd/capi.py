@@ -158,6 +158,15 @@ def declare(lib) -> None:
     lib.pagk_post_filter.restype = C.c_int
     lib.pagk_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     f32 = C.c_float
+    for name in ("pagk_graph_begin",):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [vp]
+    lib.pagk_graph_end.restype = C.c_int
+    lib.pagk_graph_end.argtypes = [vp, _P(i32)]
+    lib.pagk_graph_launch.restype = C.c_int
+    lib.pagk_graph_launch.argtypes = [vp, i32]
+    lib.pagk_graph_destroy.restype = C.c_int
+    lib.pagk_graph_destroy.argtypes = [vp, i32]
     lib.pagk_geometry_scores_device.restype = C.c_int
     lib.pagk_geometry_scores_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, vp]
     lib.pagk_geometry_scores.restype = C.c_int
@@ -174,6 +183,7 @@ EXPORTED_SYMBOLS = [
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
     "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
+    "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
 ]
 
 
@@ -324,6 +334,21 @@ class Context:
         if rc < 0:
             self._check(rc, "pagk_geometry_validation")
         return rc, st, np.float32(ts.value)
+
+    # hipGraph capture of the *_device calls issued on the context stream --------------------
+    def graph_begin(self):
+        self._check(self.lib.pagk_graph_begin(self.h), "pagk_graph_begin")
+
+    def graph_end(self) -> int:
+        gid = C.c_int32(-1)
+        self._check(self.lib.pagk_graph_end(self.h, C.byref(gid)), "pagk_graph_end")
+        return gid.value
+
+    def graph_launch(self, graph_id: int):
+        self._check(self.lib.pagk_graph_launch(self.h, graph_id), "pagk_graph_launch")
+
+    def graph_destroy(self, graph_id: int):
+        self._check(self.lib.pagk_graph_destroy(self.h, graph_id), "pagk_graph_destroy")
 
     def sync(self):
         self._check(self.lib.pagk_sync(self.h), "pagk_sync")

@@ -45,6 +45,12 @@ struct pagk_ctx {
     FrameSlot slots[kSlots];
     FeatBuf feat;
     FeatBuf score;  // scratch of the host-buffer geometry scoring path
+    // hipGraph capture of the per-frame work (pagk_graph_*): while capturing, nothing may allocate and the
+    // timing events are left out (an event recorded into a graph cannot be read back)
+    bool capturing = false;
+    static constexpr int kGraphs = 8;
+    hipGraph_t graphs[kGraphs] = {};
+    hipGraphExec_t graph_execs[kGraphs] = {};
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
@@ -66,6 +72,15 @@ namespace {
             snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,     \
                      hipGetErrorString(e_));                                                           \
             return e_ == hipErrorOutOfMemory ? PAGK_E_NOMEM : PAGK_E_HIP;                              \
+        }                                                                                              \
+    } while (0)
+
+// Entry points that copy from / to host memory or synchronise cannot be part of a graph capture.
+#define NOT_WHILE_CAPTURING(ctx, what)                                                                 \
+    do {                                                                                               \
+        if ((ctx)->capturing) {                                                                        \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s is not capturable: use the *_device entry points between pagk_graph_begin and pagk_graph_end", what); \
+            return PAGK_E_ARG;                                                                         \
         }                                                                                              \
     } while (0)
 
@@ -101,6 +116,10 @@ int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
         total = align_up(total + (size_t)lw[l] * lh[l] * 4, 256);
     }
     if (total > s.block_bytes) {
+        if (ctx->capturing) {  // run the same calls once before pagk_graph_begin so that nothing allocates here
+            snprintf(ctx->err, sizeof(ctx->err), "frame slot would have to be (re)allocated during graph capture");
+            return PAGK_E_ARG;
+        }
         if (s.block) HIPCHK(ctx, hipFree(s.block));
         s.block = nullptr;
         s.block_bytes = 0;
@@ -124,7 +143,7 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     int lw[kMaxLevels], lh[kMaxLevels];
     level_dims(s.w, s.h, s.L, lw, lh);
     dim3 blk(32, 8);
-    if (ctx->ev_pyr[0]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
+    if (ctx->ev_pyr[0] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
     if (s.L <= 4 && !ctx->unfused_pyramid) {
         PyrArgs pa;
         memset(&pa, 0, sizeof pa);
@@ -147,8 +166,8 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
         for (int l = s.L; l < 4; l++) pa.first_block[l] = nb;  // empty ranges for absent levels
         hipLaunchKernelGGL(k_pyramid_fused, dim3(nb), dim3(256), 0, ctx->stream, pa);
         HIPCHK(ctx, hipGetLastError());
-        if (ctx->ev_pyr[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
-        ctx->pyr_timed = true;
+        if (ctx->ev_pyr[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+        if (!ctx->capturing) ctx->pyr_timed = true;
         s.wrap0 = wrap0;
         s.valid = true;
         return PAGK_OK;
@@ -167,8 +186,8 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
                            s.quad[l]);
     }
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->ev_pyr[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
-    ctx->pyr_timed = true;
+    if (ctx->ev_pyr[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+    if (!ctx->capturing) ctx->pyr_timed = true;
     s.wrap0 = wrap0;
     s.valid = true;
     return PAGK_OK;
@@ -248,7 +267,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.k1 = p->dist_coef[0], a.k2 = p->dist_coef[1], a.p1 = p->dist_coef[2], a.p2 = p->dist_coef[3];
     a.k3 = p->n_dist_coef == 5 ? p->dist_coef[4] : 0.0f;
 
-    if (ctx->ev_trk[0]) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
+    if (ctx->ev_trk[0] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
     if (n > 0) {
         const int Pm = (2 * a.half + 1) * (2 * a.half + 1);
         // MFMA variant: instantiated for the common patch sizes; chosen explicitly (kernel 2) or,
@@ -319,8 +338,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         }
         HIPCHK(ctx, hipGetLastError());
     }
-    if (ctx->ev_trk[1]) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[1], ctx->stream));
-    ctx->trk_timed = true;
+    if (ctx->ev_trk[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[1], ctx->stream));
+    if (!ctx->capturing) ctx->trk_timed = true;
     return PAGK_OK;
 }
 
@@ -505,6 +524,11 @@ void pagk_destroy(pagk_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (int k = 0; k < pagk_ctx::kGraphs; k++)
+        if (ctx->graph_execs[k]) {
+            (void)hipGraphExecDestroy(ctx->graph_execs[k]);
+            (void)hipGraphDestroy(ctx->graphs[k]);
+        }
     for (auto &s : ctx->slots)
         if (s.block) (void)hipFree(s.block);
     if (ctx->feat.block) (void)hipFree(ctx->feat.block);
@@ -534,6 +558,7 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 int pagk_sync(pagk_ctx *ctx)
 {
     if (!ctx) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_sync");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PAGK_OK;
 }
@@ -541,6 +566,7 @@ int pagk_sync(pagk_ctx *ctx)
 int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms)
 {
     if (!ctx) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_last_kernel_ms");
     if (track_ms) {
         *track_ms = 0.0f;
         if (ctx->trk_timed) {
@@ -563,6 +589,7 @@ static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, 
 int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
 {
     if (!ctx || slot < 0 || slot >= kUserSlots) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_frame_upload");
     return frame_upload_any(ctx, slot, img, pyramids);
 }
 
@@ -598,6 +625,7 @@ int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_
                               int32_t *height)
 {
     if (!ctx || slot < 0 || slot >= kUserSlots || !dst) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_frame_download_level");
     FrameSlot &s = ctx->slots[slot];
     if (!s.valid || level < 1 || level >= s.L) return PAGK_E_ARG;  // level 0 is the caller's own image
     int lw[kMaxLevels], lh[kMaxLevels];
@@ -633,6 +661,7 @@ int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref, 
                const pagk_outputs *out)
 {
     if (!ctx) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_track");
     int rc = check_params(params);
     if (rc) return rc;
     if ((rc = check_image(ref)) || (rc = check_image(cur))) return rc;
@@ -648,6 +677,7 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
                    const float *affine, const uint8_t *status_in, const pagk_outputs *out)
 {
     if (!ctx || !ref_levels || !cur_levels) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_track_pyr");
     int rc = check_params(params);
     if (rc) return rc;
     if (n_levels != params->pyramids) return PAGK_E_ARG;
@@ -779,6 +809,67 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm, co
 }
 
 
+// ---- hipGraph capture of the per-frame work ---------------------------------------------------
+// BASELINE configs[4] ("hipGraph-captured iterate"): a camera stream issues the same launches with the same
+// device pointers every frame (new frame written into a fixed device buffer -> pyramid -> prediction ->
+// tracking -> scoring), so they are recorded once and replayed with one hipGraphLaunch.
+int pagk_graph_begin(pagk_ctx *ctx)
+{
+    if (!ctx || ctx->capturing) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return PAGK_OK;
+}
+
+int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
+{
+    if (!ctx || !ctx->capturing || !graph_id) return PAGK_E_ARG;
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &g));
+    int id = -1;
+    for (int k = 0; k < pagk_ctx::kGraphs; k++)
+        if (!ctx->graph_execs[k]) {
+            id = k;
+            break;
+        }
+    if (id < 0 || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        snprintf(ctx->err, sizeof(ctx->err), id < 0 ? "all %d graph slots are in use" : "capture produced no graph (%d)", pagk_ctx::kGraphs);
+        return PAGK_E_ARG;
+    }
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        snprintf(ctx->err, sizeof(ctx->err), "hipGraphInstantiate -> %s", hipGetErrorString(e));
+        return PAGK_E_HIP;
+    }
+    ctx->graphs[id] = g;
+    ctx->graph_execs[id] = ex;
+    *graph_id = id;
+    return PAGK_OK;
+}
+
+int pagk_graph_launch(pagk_ctx *ctx, int32_t graph_id)
+{
+    if (!ctx || ctx->capturing || graph_id < 0 || graph_id >= pagk_ctx::kGraphs || !ctx->graph_execs[graph_id]) return PAGK_E_ARG;
+    HIPCHK(ctx, hipGraphLaunch(ctx->graph_execs[graph_id], ctx->stream));
+    return PAGK_OK;
+}
+
+int pagk_graph_destroy(pagk_ctx *ctx, int32_t graph_id)
+{
+    if (!ctx || graph_id < 0 || graph_id >= pagk_ctx::kGraphs || !ctx->graph_execs[graph_id]) return PAGK_E_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipGraphExecDestroy(ctx->graph_execs[graph_id]);
+    (void)hipGraphDestroy(ctx->graphs[graph_id]);
+    ctx->graph_execs[graph_id] = nullptr;
+    ctx->graphs[graph_id] = nullptr;
+    return PAGK_OK;
+}
+
 // ---- geometry validation scoring ----------------------------------
 int pagk_geometry_scores_device(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
                                 int32_t n, const float *d_pts1, const float *d_pts2, float sigma,
@@ -802,6 +893,7 @@ int pagk_geometry_scores(pagk_ctx *ctx, const double *H21, const double *H12, co
                          uint8_t *inliers_F, float *score_H, float *score_F)
 {
     if (!ctx || !H21 || !H12 || !F21 || n < 0 || !score_H || !score_F) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_geometry_scores");
     if (n > 0 && (!pts1 || !pts2 || !inliers_H || !inliers_F)) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)(n < 1 ? 1 : n);

@@ -26,15 +26,18 @@ class ResidentTracker:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.ctx = capi.Context(device)
-        # run on torch's current stream so that torch.cuda.Event / torch.distributed order with us
-        self.main = torch.cuda.current_stream(self.dev)   # the stream current at construction time
-        self.ctx.set_stream(self.main.cuda_stream)
-        # side stream: the NEXT frame's pyramid is built while the current pair is being tracked (a
-        # new frame's pyramid does not depend on any tracking result)
+        # Two explicit streams.  `main` carries the tracking launches (and, because step() makes it torch's
+        # current stream, the RCCL all-gather orders after them); `side` builds the NEXT frame's pyramid while
+        # the current pair is being tracked (a new frame's pyramid depends on no tracking result).  Never the
+        # legacy default stream: its handle is 0, which pagk_set_stream reads as "the context's own stream",
+        # and it cannot be captured into a hipGraph.
+        self.main = torch.cuda.Stream(device=self.dev)
         self.side = torch.cuda.Stream(device=self.dev)
+        self.ctx.set_stream(self.main.cuda_stream)
         self.cur_slot = 1           # slots 1 / 2 alternate as "current frame"
         self._pyr_ready = None      # event: pyramid of the frame to track next is built
         self._trk_done = {1: None, 2: None}  # event per slot: last tracking kernel that read it
+        self._graph = None          # captured [pyramid -> PatchMatch] of step(graph=True)
         self.n = 0
 
     def close(self):
@@ -50,6 +53,18 @@ class ResidentTracker:
         self.ctx.frame_set_device(1, self.img_cur.data_ptr(), w, h, w, L)
         self.ctx.frame_set_device(2, self.img_cur.data_ptr(), w, h, w, L)
         self.cur_slot, self._pyr_ready = 1, None
+        self._drop_graph()
+        self._settle()
+
+    def _settle(self):
+        """Set-up work ran on torch's current stream and on `main`: let both finish before steps start."""
+        torch.cuda.synchronize(self.dev)
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            for gid in self._graph:
+                self.ctx.graph_destroy(gid)
+            self._graph = None
 
     def set_features(self, pt_ref, pt_init, affine, status_in):
         """Takes the FULL feature arrays; keeps this rank's contiguous shard on the device."""
@@ -70,6 +85,8 @@ class ResidentTracker:
         self.d_affine = up(affine, 4)
         self.d_status = up(status_in, 1)
         self.out = distributed.alloc_device_outputs(m, self.dev)
+        self._drop_graph()
+        self._settle()
 
     def rebuild_current_pyramid(self, slot: int = 1):
         self.ctx.frame_set_device(slot, self.img_cur.data_ptr(), self.w, self.h, self.w, self.params.pyramids)
@@ -90,28 +107,88 @@ class ResidentTracker:
         self.ctx.set_stream(self.main.cuda_stream)
         return ev
 
-    def step(self, gather: bool = True, overlap: bool = True):
+    def step(self, gather: bool = True, mode: str = "graph"):
         """One pass of the hot path over this rank's shard (+ the result all-gather): pyramid of the
-        current frame, PatchMatch.  With overlap (default) the pyramid of step k+1's frame is built on a
-        side stream while step k tracks; every step still builds exactly one pyramid and runs one
-        tracking launch."""
-        if not overlap:
-            self.rebuild_current_pyramid(1)
-            self.track_shard(1)
-        else:
-            if self._pyr_ready is None:                       # first step: nothing prefetched yet
+        current frame, then PatchMatch.  `mode` only chooses how the two launches reach the GPU; every
+        mode builds exactly one pyramid and runs one tracking launch per step (measured on MI355X,
+        752x480 / 1000 features, tools/graph_fork.py, profiles/r01_step_modes.log):
+          "graph"   (default) one hipGraphLaunch replaying [pyramid -> PatchMatch], captured on first use
+                    (BASELINE configs[4]: "hipGraph-captured iterate"): no inter-launch gap, 121.7 us;
+          "serial"  the same two launches issued directly on one stream: 132.9 us (5 us gap per launch);
+          "streams" pyramid of step k+1's frame on a side stream while step k tracks, ordered by events:
+                    134.6 us -- a cross-stream event wait costs more than the 7.7 us pyramid it hides;
+          "fork"    that overlap as two branches of one graph: 143.6 us."""
+        graph = {"graph": True, "fork": "fork"}.get(mode, False)
+        overlap = mode == "streams"
+        if mode not in ("graph", "fork", "serial", "streams"):
+            raise ValueError(mode)
+        with torch.cuda.stream(self.main):
+            if graph:
+                self._graph_step(fork=(graph == "fork"))
+            elif not overlap:
+                self.rebuild_current_pyramid(1)
+                self.track_shard(1)
+            else:
+                if self._pyr_ready is None:                       # first step: nothing prefetched yet
+                    self._pyr_ready = self._prefetch_pyramid(self.cur_slot)
+                self.main.wait_event(self._pyr_ready)
+                slot = self.cur_slot
+                self.track_shard(slot)
+                done = torch.cuda.Event()
+                done.record(self.main)
+                self._trk_done[slot] = done
+                self.cur_slot = 3 - slot                          # 1 <-> 2
                 self._pyr_ready = self._prefetch_pyramid(self.cur_slot)
-            self.main.wait_event(self._pyr_ready)
-            slot = self.cur_slot
-            self.track_shard(slot)
-            done = torch.cuda.Event()
-            done.record(self.main)
-            self._trk_done[slot] = done
-            self.cur_slot = 3 - slot                          # 1 <-> 2
-            self._pyr_ready = self._prefetch_pyramid(self.cur_slot)
-        if gather and (self.world > 1 or distributed.FORCE_COLLECTIVE):
-            res = distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
-            if isinstance(res, distributed.Gathered):
-                self._gather_buf = res.raw
-            return res
+            if gather and (self.world > 1 or distributed.FORCE_COLLECTIVE):
+                res = distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
+                if isinstance(res, distributed.Gathered):
+                    self._gather_buf = res.raw
+                return res
         return {name: self.out[name][:self.hi - self.lo] for name, _, _ in distributed.FIELDS}
+
+    def _graph_step(self, fork: bool):
+        """Replay (capturing on first use) the step as a hipGraph.  Linear form: [pyramid(slot 1) ->
+        PatchMatch(0, 1)].  Fork form: two graphs, one per parity, each [PatchMatch(0, cur) || pyramid(next)]
+        -- the side-stream prefetch of step() expressed as two independent branches of one graph."""
+        if self._graph is None:
+            self.rebuild_current_pyramid(1)      # warm-up: allocations, kernel attributes
+            self.rebuild_current_pyramid(2)
+            self.track_shard(1)
+            self.main.synchronize()
+            if not fork:
+                self.ctx.graph_begin()
+                try:
+                    self.rebuild_current_pyramid(1)
+                    self.track_shard(1)
+                finally:
+                    self._graph = (self.ctx.graph_end(),)
+            else:
+                ids = []
+                for cur in (1, 2):
+                    self.ctx.graph_begin()       # capture starts on `main`
+                    try:
+                        e1 = torch.cuda.Event()
+                        e1.record(self.main)
+                        self.side.wait_event(e1)                 # fork: `side` joins the capture
+                        self.ctx.set_stream(self.side.cuda_stream)
+                        self.rebuild_current_pyramid(3 - cur)    # next frame's pyramid
+                        self.ctx.set_stream(self.main.cuda_stream)
+                        self.track_shard(cur)
+                        e2 = torch.cuda.Event()
+                        e2.record(self.side)
+                        self.main.wait_event(e2)                 # join
+                    finally:
+                        self.ctx.set_stream(self.main.cuda_stream)
+                        ids.append(self.ctx.graph_end())
+                self._graph = tuple(ids)
+                self.cur_slot = 1
+        if len(self._graph) == 1:
+            self.ctx.graph_launch(self._graph[0])
+        else:
+            self.ctx.graph_launch(self._graph[self.cur_slot - 1])
+            self.cur_slot = 3 - self.cur_slot
+
+    def synchronize(self):
+        """Wait for everything step() has issued (tracking on `main`, prefetch on `side`)."""
+        self.main.synchronize()
+        self.side.synchronize()

@@ -336,3 +336,97 @@ def test_full_size_properties_1080p_20000(ctx):
     # skipped features: untouched initial point, zero outputs
     sk = w.status_in == 0
     assert not a["status"][:n][sk].any() and np.all(a["pix_err"][:n][sk] == 0)
+
+
+# ---- hipGraph-captured iterate (BASELINE configs[4]) ---------------------------------------------------
+def test_graph_replay_matches_direct_launches_on_the_720p_stream_shape(ctx):
+    w = synth.config(4, n=1500)          # 1280x720 stream shape, reduced feature count
+    p = params_for(w)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+    for _ in range(3):                   # first call captures, the others replay
+        out = rt.step(mode="graph")
+    rt.synchronize()
+    assert rt._graph is not None
+    assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what="graph replay")
+    # a new frame written into the SAME device buffer is picked up by the next replay (the graph holds
+    # pointers, not pixels): swap the two images' roles
+    with torch.cuda.stream(rt.main):
+        tmp = rt.img_cur.clone()
+        rt.img_cur.copy_(rt.img_ref)     # current := old reference  (pyramid node reads img_cur)
+        rt.ctx.frame_set_device(0, tmp.data_ptr(), rt.w, rt.h, rt.w, p.pyramids)   # reference := old current
+        out = rt.step(mode="graph")
+    rt.synchronize()
+    swapped = orc.track(p, w.img_cur, w.img_ref, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+    assert_parity(distributed.to_numpy(out), swapped, w.n, exact=True, what="graph replay on a new frame")
+    rt.close()
+
+
+def test_graph_capture_rules(ctx):
+    w = synth.config(1, n=64)
+    p = params_for(w)
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+    c = rt.ctx
+    with pytest.raises(capi.PagkError):
+        c.graph_launch(0)                                   # nothing captured yet
+    big = torch.zeros((960, 1504), dtype=torch.uint8, device="cuda")   # allocated BEFORE the capture starts
+    torch.cuda.synchronize()
+    c.graph_begin()
+    try:
+        with pytest.raises(capi.PagkError) as e:            # host-buffer entry points are not capturable
+            c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert e.value.code == capi.PAGK_E_ARG
+        with pytest.raises(capi.PagkError):                 # a bigger frame slot would have to allocate
+            c.frame_set_device(3, big.data_ptr(), 1504, 960, 1504, 3)
+        with pytest.raises(capi.PagkError):
+            c.graph_begin()                                 # no nesting
+        rt.track_shard(1)
+    finally:
+        gid = c.graph_end()
+    c.graph_launch(gid)
+    rt.synchronize()
+    got = {k: rt.out[k].cpu().numpy() for k, _, _ in distributed.FIELDS}
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert_parity(got, ref, w.n, exact=True, what="captured track_device")
+    c.graph_destroy(gid)
+    with pytest.raises(capi.PagkError):
+        c.graph_launch(gid)
+    rt.close()
+
+
+def test_rccl_all_gather_is_ordered_after_the_tracking_launch(ctx):
+    # One-rank RCCL group on the GPU: the gather must ship THIS step's results (stream ordering between the
+    # graph replay on the tracker's stream and the collective), checked by changing the inputs between steps.
+    import os
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    distributed.FORCE_COLLECTIVE = True
+    try:
+        w = synth.config(1, n=700)
+        p = params_for(w)
+        rt = runtime.ResidentTracker(p, device=0)
+        rt.load_pair(w.img_ref, w.img_cur)
+        for k, shift in enumerate((0.0, 0.75, -1.5)):
+            init = (w.pt_init + np.float32(shift)).astype(np.float32)
+            rt.set_features(w.pt_ref, init, w.affine, w.status_in)
+            res = rt.step()                       # graph captured anew after set_features
+            assert isinstance(res, distributed.Gathered)
+            rt.synchronize()
+            torch.cuda.synchronize()
+            got = distributed.to_numpy(res)
+            ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, init, w.affine, w.status_in, nthreads=16)
+            assert_parity(got, ref, w.n, exact=True, what=f"gathered results of step {k}")
+        rt.close()
+    finally:
+        distributed.FORCE_COLLECTIVE = False
+        dist.destroy_process_group()
