@@ -430,3 +430,42 @@ def test_rccl_all_gather_is_ordered_after_the_tracking_launch(ctx):
     finally:
         distributed.FORCE_COLLECTIVE = False
         dist.destroy_process_group()
+
+
+# ---- randomized sweep: every knob of the path drawn at random, all four kernels ---------------------------
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(1, 5))
+    mult = 1 << (L - 1)                                  # parents even through all levels (exact-2x resize path)
+    h = int(rng.integers(1, 13))
+    wmin = (2 * h + 8 + mult - 1) // mult                # the coarsest level still holds a patch
+    width = mult * int(rng.integers(max(wmin, 12), 60))
+    height = mult * int(rng.integers(max(wmin, 10), 45))
+    n = int(rng.integers(1, 300))
+    motion = "rotation" if rng.random() < 0.7 else "translation"
+    w = synth.make_workload("rnd", width, height, n, seed=int(rng.integers(1 << 30)), half_patch=h,
+                            iterations=int(rng.integers(1, 31)), pyramids=L, motion=motion,
+                            has_gyro=motion == "rotation", omega=tuple(rng.uniform(-1.5, 1.5, 3)),
+                            translation=tuple(rng.uniform(-3, 3, 2)), edge_fraction=float(rng.choice([0.0, 0.3, 1.0])),
+                            gain=float(rng.uniform(0.8, 1.25)), offset=float(rng.uniform(-10, 10)))
+    w.status_in[rng.random(n) < 0.1] = 0
+    flags = dict(illumination=bool(rng.integers(2)), affine=bool(rng.integers(2)), penalty=bool(rng.integers(2)),
+                 ncc=bool(rng.random() < 0.25))
+    return w, flags
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_parity_sweep(ctx, seed):
+    w, flags = _random_case(0xA11CE + seed)
+    p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
+                         camera=w.camera, **flags)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
+    for kernel in (0, 1, 2, 3):   # auto, thread-per-feature, MFMA 2-wave, wave-per-feature (fall back where not built)
+        ctx.set_kernel(kernel)
+        try:
+            got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        finally:
+            ctx.set_kernel(0)
+        what = (f"seed {seed} kernel {kernel}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} n={w.n} h={w.half_patch} "
+                f"L={w.pyramids} it={w.iterations} {flags}")
+        assert_parity(got, ref, w.n, exact=True, what=what)
