@@ -117,16 +117,60 @@ static inline float get_pixel_value(const level_t *img, float x, float y)
  * INTER_LINEAR.  THIRD PARTY (OpenCV >= 3.4, not vendored): for an exact 2x decimation
  * of 8UC1, resize() switches INTER_LINEAR to the INTER_AREA fast path, whose 8-bit
  * kernel is (s00 + s01 + s10 + s11 + 2) >> 2.  Odd parent sizes take OpenCV's 11-bit
- * fixed-point bilinear path, which is not restated: the oracle refuses them. */
+ * fixed-point bilinear path (second half of the function). */
 int pagk_oracle_pyr_down(const uint8_t *src, int32_t w, int32_t h, int64_t step, uint8_t *dst)
 {
-    if (!src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1) || step < w) return PAGK_E_ARG;
-    int dw = w / 2, dh = h / 2;
-    for (int y = 0; y < dh; y++) {
-        const uint8_t *r0 = src + (int64_t)(2 * y) * step, *r1 = r0 + step;
-        for (int x = 0; x < dw; x++)
-            dst[(int64_t)y * dw + x] =
-                (uint8_t)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2);
+    if (!src || !dst || w < 2 || h < 2 || step < w) return PAGK_E_ARG;
+    /* :69  cv::Size(cols * 0.5, rows * 0.5): int * double, truncated */
+    const int dw = (int)(w * 0.5), dh = (int)(h * 0.5);
+    if (!((w & 1) || (h & 1))) { /* scale exactly 2 in x and y: INTER_AREA fast path */
+        for (int y = 0; y < dh; y++) {
+            const uint8_t *r0 = src + (int64_t)(2 * y) * step, *r1 = r0 + step;
+            for (int x = 0; x < dw; x++)
+                dst[(int64_t)y * dw + x] =
+                    (uint8_t)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2);
+        }
+        return PAGK_OK;
+    }
+    /* Any other size: OpenCV's INTER_LINEAR for 8-bit images, 11-bit fixed-point coefficients
+     * (imgproc/resize.cpp of OpenCV 3.4, restated FROM MEMORY -- parity unpinned, see oracle/README.md):
+     *   scale = 1 / (dsize / (double)ssize);  f = (float)((d + 0.5) * scale - 0.5);  s = cvFloor(f);  f -= s;
+     *   s < 0 -> (f, s) = (0, 0);   s >= ssize - 1 -> (f, s) = (0, ssize - 1), single tap;
+     *   coefficients saturate_cast<short>((1 - f) * 2048), saturate_cast<short>(f * 2048)  (cvRound: nearest even);
+     *   horizontal pass in int: S[s] * a0 + S[s + 1] * a1  (a single tap is S[s] * 2048);
+     *   vertical pass (VResizeLinear<uchar, int, short>): ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2,
+     *   the second row index clipped to the last row. */
+    const double scale_x = 1. / ((double)dw / w), scale_y = 1. / ((double)dh / h);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const int b0 = (int)lrintf((1.f - fy) * 2048.f), b1 = (int)lrintf(fy * 2048.f);
+        /* rows sy and sy + 1, each clipped into [0, h - 1] */
+        int y0 = sy < 0 ? 0 : (sy < h ? sy : h - 1);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 < h ? sy + 1 : h - 1);
+        const uint8_t *r0 = src + (int64_t)y0 * step, *r1 = src + (int64_t)y1 * step;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            int single = 0;
+            if (sx < 0) fx = 0, sx = 0;
+            if (sx + 1 >= w) { /* dx >= xmax */
+                single = 1;
+                if (sx >= w - 1) fx = 0, sx = w - 1;
+            }
+            const int a0 = (int)lrintf((1.f - fx) * 2048.f), a1 = (int)lrintf(fx * 2048.f);
+            int S0, S1;
+            if (single) {
+                S0 = r0[sx] * 2048;
+                S1 = r1[sx] * 2048;
+            } else {
+                S0 = r0[sx] * a0 + r0[sx + 1] * a1;
+                S1 = r1[sx] * a0 + r1[sx + 1] * a1;
+            }
+            dst[(int64_t)dy * dw + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+        }
     }
     return PAGK_OK;
 }
@@ -592,7 +636,7 @@ static int build_pyramid(const pagk_image *im, int n_levels, level_t *lv, uint8_
         const level_t *pv = &lv[l - 1];
         /* :69  cv::Size(cols * 0.5, rows * 0.5): int*double truncated */
         int dw = (int)(pv->cols * 0.5), dh = (int)(pv->rows * 0.5);
-        if ((pv->cols & 1) || (pv->rows & 1) || dw < 1 || dh < 1) return PAGK_E_UNSUPPORTED;
+        if (pv->cols < 2 || pv->rows < 2 || dw < 1 || dh < 1) return PAGK_E_ARG;
         owned[l] = (uint8_t *)malloc((size_t)dw * (size_t)dh);
         if (!owned[l]) return PAGK_E_NOMEM;
         pagk_oracle_pyr_down(pv->data, pv->cols, pv->rows, pv->step, owned[l]);

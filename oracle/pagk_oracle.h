@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-/* cv::resize(src, dst, Size(cols*0.5, rows*0.5)) for an even-sized 8UC1 image
- * (reference src/patch_match.cpp:69-70).  dst is (w/2) x (h/2), contiguous. */
+/* cv::resize(src, dst, Size(cols*0.5, rows*0.5)) of an 8UC1 image, default INTER_LINEAR
+ * (reference src/patch_match.cpp:69-70): the exact-2x case is OpenCV's INTER_AREA fast path, any
+ * other (odd) size its 11-bit fixed-point bilinear.  dst is (int)(w*0.5) x (int)(h*0.5), contiguous. */
 int pagk_oracle_pyr_down(const uint8_t *src, int32_t w, int32_t h, int64_t step, uint8_t *dst);
 
 /* PatchMatch::OpticalFlowMultiLevel (src/patch_match.cpp:79-142) on host buffers;

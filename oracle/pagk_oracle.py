@@ -69,7 +69,7 @@ def _p(a):
 
 def pyr_down(img: np.ndarray) -> np.ndarray:
     h, w = img.shape
-    out = np.zeros((h // 2, w // 2), np.uint8)
+    out = np.zeros((int(h * 0.5), int(w * 0.5)), np.uint8)
     rc = load().pagk_oracle_pyr_down(img.ctypes.data, w, h, img.strides[0], out.ctypes.data)
     if rc:
         raise RuntimeError(f"pagk_oracle_pyr_down: {rc}")

@@ -91,9 +91,7 @@ int level_dims(int w, int h, int L, int *lw, int *lh)
     lw[0] = w;
     lh[0] = h;
     for (int l = 1; l < L; l++) {
-        // src/patch_match.cpp:69  cv::Size(cols * 0.5, rows * 0.5); only the exact-2x path of
-        // cv::resize is implemented: parents must be even.
-        if ((lw[l - 1] & 1) || (lh[l - 1] & 1)) return PAGK_E_UNSUPPORTED;
+        // src/patch_match.cpp:69  cv::Size(cols * 0.5, rows * 0.5)
         lw[l] = (int)(lw[l - 1] * 0.5);
         lh[l] = (int)(lh[l - 1] * 0.5);
         if (lw[l] < 1 || lh[l] < 1) return PAGK_E_ARG;
@@ -144,7 +142,11 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     level_dims(s.w, s.h, s.L, lw, lh);
     dim3 blk(32, 8);
     if (ctx->ev_pyr[0] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
-    if (s.L <= 4 && !ctx->unfused_pyramid) {
+    // the fused kernel re-derives every level from level 0 by nested 2x2 means: valid while every parent is
+    // even in both dimensions (the exact-2x case of cv::resize); otherwise level by level
+    bool all_even = true;
+    for (int l = 0; l + 1 < s.L; l++) all_even = all_even && !(lw[l] & 1) && !(lh[l] & 1);
+    if (s.L <= 4 && !ctx->unfused_pyramid && all_even) {
         PyrArgs pa;
         memset(&pa, 0, sizeof pa);
         pa.src = src0;
@@ -177,7 +179,11 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     for (int l = 0; l < s.L; l++) {
         if (l > 0) {
             dim3 grd((lw[l] + 31) / 32, (lh[l] + 7) / 8);
-            hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, ctx->stream, src, pitch, lw[l], lh[l], s.u8[l]);
+            if (!(lw[l - 1] & 1) && !(lh[l - 1] & 1))
+                hipLaunchKernelGGL(k_pyr_down, grd, blk, 0, ctx->stream, src, pitch, lw[l], lh[l], s.u8[l]);
+            else
+                hipLaunchKernelGGL(k_pyr_down_linear, grd, blk, 0, ctx->stream, src, pitch, lw[l - 1], lh[l - 1], lw[l],
+                                   lh[l], 1. / ((double)lw[l] / lw[l - 1]), 1. / ((double)lh[l] / lh[l - 1]), s.u8[l]);
             src = s.u8[l];
             pitch = lw[l];
         }

@@ -34,6 +34,43 @@ __global__ void k_pyr_down(const uint8_t *__restrict__ src, int64_t pitch, int d
     dst[(int64_t)y * dw + x] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
 }
 
+// The same cv::resize for a parent with an odd dimension: OpenCV's INTER_LINEAR for 8-bit images with
+// 11-bit fixed-point coefficients (restated from memory of OpenCV 3.4 imgproc/resize.cpp -- parity
+// unpinned; operation for operation the oracle's pagk_oracle_pyr_down).  One thread per output pixel.
+__global__ void k_pyr_down_linear(const uint8_t *__restrict__ src, int64_t pitch, int w, int h, int dw, int dh,
+                                  double scale_x, double scale_y, uint8_t *__restrict__ dst)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);  // cvRound
+    const int y0 = sy < 0 ? 0 : (sy < h ? sy : h - 1);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < h ? sy + 1 : h - 1);
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    bool single = false;
+    if (sx < 0) fx = 0.f, sx = 0;
+    if (sx + 1 >= w) {
+        single = true;
+        if (sx >= w - 1) fx = 0.f, sx = w - 1;
+    }
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    const uint8_t *r0 = src + (int64_t)y0 * pitch, *r1 = src + (int64_t)y1 * pitch;
+    int S0, S1;
+    if (single) {
+        S0 = (int)r0[sx] * 2048;
+        S1 = (int)r1[sx] * 2048;
+    } else {
+        S0 = (int)r0[sx] * a0 + (int)r0[sx + 1] * a1;
+        S1 = (int)r1[sx] * a0 + (int)r1[sx + 1] * a1;
+    }
+    dst[(int64_t)dy * dw + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+
 // Packs the taps of GetPixelValue for every pixel (see DevLevel).  `wrap` = the source
 // image is continuous (step == cols): data[off+1] of the last column is the next row's
 // first pixel.  Otherwise that byte is row padding, defined as 0.  Rows past the image = 0.

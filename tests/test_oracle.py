@@ -135,7 +135,33 @@ def test_oracle_rejects_unsupported(built):
     p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=False, inverse=True)
     with pytest.raises(RuntimeError):
         orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
-    p = capi.make_params(half_patch=5, iterations=10, pyramids=3, has_gyro=False)
-    odd = np.zeros((121, 161), np.uint8)
-    with pytest.raises(RuntimeError):   # odd parent size: OpenCV's general bilinear path is not restated
-        orc.track(p, odd, odd, w.pt_ref, w.pt_init, w.affine, w.status_in)
+
+
+def test_odd_sized_pyramid_levels(built):
+    # parents with an odd dimension take OpenCV's 11-bit fixed-point bilinear resize (restated from memory,
+    # parity unpinned): within one grey level of the exact bilinear value, dims truncated like cv::Size(int*0.5)
+    rng = np.random.default_rng(0)
+    for (h, w_) in [(121, 161), (120, 161), (121, 160), (7, 9), (3, 3), (2, 3), (375, 1241)]:
+        img = rng.integers(0, 256, (h, w_), dtype=np.uint8)
+        d = orc.pyr_down(img)
+        dh, dw = int(h * 0.5), int(w_ * 0.5)
+        assert d.shape == (dh, dw)
+        ys = (np.arange(dh) + 0.5) * (h / dh) - 0.5
+        xs = (np.arange(dw) + 0.5) * (w_ / dw) - 0.5
+        y0 = np.clip(np.floor(ys).astype(int), 0, h - 1)
+        x0 = np.clip(np.floor(xs).astype(int), 0, w_ - 1)
+        y1, x1 = np.clip(y0 + 1, 0, h - 1), np.clip(x0 + 1, 0, w_ - 1)
+        fy, fx = (ys - np.floor(ys))[:, None], (xs - np.floor(xs))[None, :]
+        f = img.astype(np.float64)
+        ref = (1 - fy) * ((1 - fx) * f[y0][:, x0] + fx * f[y0][:, x1]) + fy * ((1 - fx) * f[y1][:, x0] + fx * f[y1][:, x1])
+        assert np.abs(d.astype(np.float64) - ref).max() < 1.0
+    # constant images stay constant (coefficients sum to 2048 exactly) and the even case is the 2x2 mean
+    assert (orc.pyr_down(np.full((9, 11), 200, np.uint8)) == 200).all()
+    img = rng.integers(0, 256, (8, 12), dtype=np.uint8)
+    q = img.astype(np.int32)
+    assert np.array_equal(orc.pyr_down(img), ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2))
+    # tracking runs on such images
+    w = synth.make_workload("odd", 161, 121, 40, seed=0x0DD, half_patch=5, iterations=10, pyramids=3)
+    p = capi.make_params(half_patch=5, iterations=10, pyramids=3, camera=w.camera)
+    out = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert out["status"][:40].sum() > 25
