@@ -32,6 +32,7 @@ struct FrameSlot {
 
 struct FeatBuf {
     void *block = nullptr;
+    void *host = nullptr;  // pinned mirror of `block` (host-buffer path: one copy in, one copy out)
     size_t bytes = 0;
     int cap = 0;
 };
@@ -354,6 +355,9 @@ struct FeatPtrs {
     float *pt_ref, *pt_init, *affine;
     uint8_t *status_in;
     pagk_outputs out;
+    size_t offs[11];   // byte offsets of the eleven arrays inside the block (and its pinned mirror)
+    size_t in_bytes;   // [0, in_bytes) = the four input arrays; [in_bytes, total) = the outputs
+    size_t total;
 };
 
 int feat_reserve(pagk_ctx *ctx, int n, FeatPtrs *fp)
@@ -368,11 +372,17 @@ int feat_reserve(pagk_ctx *ctx, int n, FeatPtrs *fp)
     }
     if (total > ctx->feat.bytes) {
         if (ctx->feat.block) HIPCHK(ctx, hipFree(ctx->feat.block));
+        if (ctx->feat.host) HIPCHK(ctx, hipHostFree(ctx->feat.host));
         ctx->feat.block = nullptr;
+        ctx->feat.host = nullptr;
         ctx->feat.bytes = 0;
         HIPCHK(ctx, hipMalloc(&ctx->feat.block, total));
+        HIPCHK(ctx, hipHostMalloc(&ctx->feat.host, total, hipHostMallocDefault));
         ctx->feat.bytes = total;
     }
+    for (int k = 0; k < 11; k++) fp->offs[k] = offs[k];
+    fp->in_bytes = offs[4];
+    fp->total = total;
     uint8_t *b = static_cast<uint8_t *>(ctx->feat.block);
     fp->pt_ref = reinterpret_cast<float *>(b + offs[0]);
     fp->pt_init = reinterpret_cast<float *>(b + offs[1]);
@@ -390,6 +400,8 @@ int feat_reserve(pagk_ctx *ctx, int n, FeatPtrs *fp)
 
 int upload_level0(pagk_ctx *ctx, FrameSlot &s, const pagk_image *img)
 {
+    // straight from the caller's (pageable) memory: packing the rows into a pinned buffer first and shipping
+    // one DMA measured the same (244 vs 238 us per pagk_track call, tools/host_path_time.py)
     HIPCHK(ctx, hipMemcpy2DAsync(s.u8[0], (size_t)s.w, img->data, (size_t)img->step, (size_t)s.w, (size_t)s.h,
                                  hipMemcpyHostToDevice, ctx->stream));
     return PAGK_OK;
@@ -414,12 +426,15 @@ int track_host_common(pagk_ctx *ctx, const pagk_params *p, int n, const float *p
     FeatPtrs fp;
     int rc = feat_reserve(ctx, n, &fp);
     if (rc) return rc;
+    uint8_t *hb = static_cast<uint8_t *>(ctx->feat.host), *db = static_cast<uint8_t *>(ctx->feat.block);
     if (n > 0) {
+        // gather the (up to) four input arrays into the pinned mirror, ship them with ONE copy
         size_t nn = (size_t)n;
-        HIPCHK(ctx, hipMemcpyAsync(fp.pt_ref, pt_ref, nn * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (pt_init) HIPCHK(ctx, hipMemcpyAsync(fp.pt_init, pt_init, nn * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (affine) HIPCHK(ctx, hipMemcpyAsync(fp.affine, affine, nn * 16, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(fp.status_in, status_in, nn, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(hb + fp.offs[0], pt_ref, nn * 8);
+        if (pt_init) memcpy(hb + fp.offs[1], pt_init, nn * 8);
+        if (affine) memcpy(hb + fp.offs[2], affine, nn * 16);
+        memcpy(hb + fp.offs[3], status_in, nn);
+        HIPCHK(ctx, hipMemcpyAsync(db, hb, fp.in_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     pagk_outputs dout = fp.out;
     if (!out->pt_dist) dout.pt_dist = nullptr;
@@ -430,17 +445,20 @@ int track_host_common(pagk_ctx *ctx, const pagk_params *p, int n, const float *p
     rc = launch_track(ctx, p, sr, sc, n, fp.pt_ref, pt_init ? fp.pt_init : nullptr, affine ? fp.affine : nullptr,
                       fp.status_in, &dout);
     if (rc) return rc;
+    if (n > 0)  // every output array with ONE copy into the pinned mirror, scattered to the caller after the sync
+        HIPCHK(ctx, hipMemcpyAsync(hb + fp.in_bytes, db + fp.in_bytes, fp.total - fp.in_bytes, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (n > 0) {
         size_t nn = (size_t)n;
-        HIPCHK(ctx, hipMemcpyAsync(out->pt_un, dout.pt_un, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(out->status, dout.status, nn, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->pt_dist) HIPCHK(ctx, hipMemcpyAsync(out->pt_dist, dout.pt_dist, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->pix_err) HIPCHK(ctx, hipMemcpyAsync(out->pix_err, dout.pix_err, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->dist_pred) HIPCHK(ctx, hipMemcpyAsync(out->dist_pred, dout.dist_pred, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->ncc) HIPCHK(ctx, hipMemcpyAsync(out->ncc, dout.ncc, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->iters) HIPCHK(ctx, hipMemcpyAsync(out->iters, dout.iters, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+        memcpy(out->pt_un, hb + fp.offs[4], nn * 8);
+        if (out->pt_dist) memcpy(out->pt_dist, hb + fp.offs[5], nn * 8);
+        memcpy(out->status, hb + fp.offs[6], nn);
+        if (out->pix_err) memcpy(out->pix_err, hb + fp.offs[7], nn * 8);
+        if (out->dist_pred) memcpy(out->dist_pred, hb + fp.offs[8], nn * 8);
+        if (out->ncc) memcpy(out->ncc, hb + fp.offs[9], nn * 4);
+        if (out->iters) memcpy(out->iters, hb + fp.offs[10], nn * 4);
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PAGK_OK;
 }
 
@@ -538,6 +556,7 @@ void pagk_destroy(pagk_ctx *ctx)
     for (auto &s : ctx->slots)
         if (s.block) (void)hipFree(s.block);
     if (ctx->feat.block) (void)hipFree(ctx->feat.block);
+    if (ctx->feat.host) (void)hipHostFree(ctx->feat.host);
     if (ctx->score.block) (void)hipFree(ctx->score.block);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
