@@ -80,11 +80,24 @@ class ResidentTracker:
                 t[:hi - lo] = torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(self.dev)
             return t
 
+        same_shape = getattr(self, "d_pt_ref", None) is not None and self.d_pt_ref.shape[0] == max(m, 1) \
+            and getattr(self, "_n_alloc", None) == self.n
+        if same_shape:
+            # a stream of frames with a fixed feature capacity (unused entries carry status_in = 0): new
+            # values go into the SAME device arrays, so a captured graph stays valid
+            with torch.cuda.stream(self.main):
+                for dst, a, width in ((self.d_pt_ref, pt_ref, 2), (self.d_pt_init, pt_init, 2),
+                                      (self.d_affine, affine, 4), (self.d_status, status_in, 1)):
+                    if hi > lo:
+                        dst[:hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(self.dev))
+            self._settle()
+            return
         self.d_pt_ref = up(pt_ref, 2)
         self.d_pt_init = up(pt_init, 2)
         self.d_affine = up(affine, 4)
         self.d_status = up(status_in, 1)
         self.out = distributed.alloc_device_outputs(m, self.dev)
+        self._n_alloc = self.n
         self._drop_graph()
         self._settle()
 

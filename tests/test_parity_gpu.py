@@ -375,6 +375,19 @@ def test_graph_replay_matches_direct_launches_on_the_720p_stream_shape(ctx):
     rt.synchronize()
     swapped = orc.track(p, w.img_cur, w.img_ref, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
     assert_parity(distributed.to_numpy(out), swapped, w.n, exact=True, what="graph replay on a new frame")
+    # new feature values of the same capacity go into the same device arrays: the graph is kept; a shorter
+    # list is expressed with status_in = 0 on the unused tail
+    gid = rt._graph
+    st = w.status_in.copy()
+    st[1000:] = 0
+    init = (w.pt_init + np.float32(0.5)).astype(np.float32)
+    rt.set_features(w.pt_ref, init, w.affine, st)
+    assert rt._graph == gid
+    out = rt.step(mode="graph")
+    rt.synchronize()
+    ref2 = orc.track(p, w.img_cur, w.img_ref, w.pt_ref, init, w.affine, st, nthreads=16)
+    assert_parity(distributed.to_numpy(out), ref2, w.n, exact=True, what="graph replay on new features")
+    assert not distributed.to_numpy(out)["status"][1000:].any()
     rt.close()
 
 
