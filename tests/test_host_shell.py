@@ -139,6 +139,23 @@ def test_cpp_demo_loop_over_a_sequence(built, tmp_path):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
 
+    # examples/stream_resident.cpp: the same loop on the device-resident C ABI (one frame upload per pair,
+    # prediction on the device feeding pagk_track_device) must print the same lines
+    def mul32(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    Kinv32_ = np.linalg.inv(K32.astype(np.float64)).astype(np.float32)
+    with open(path, "ab") as f:
+        for R in Rs:
+            f.write(mul32(mul32(K32, R), Kinv32_).tobytes())
+    exe2 = str(tmp_path / "stream_resident")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I",
+                    os.path.join(root, "include"), os.path.join(root, "examples", "stream_resident.cpp"), "-o", exe2,
+                    "-L", pkg, "-l:libpagk_hip.so", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r2 = subprocess.run([exe2, path, "5", "10", "3"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout.strip().splitlines() == lines
+
     # the same loop with the oracle (prediction + PatchMatch + post-filter)
     def mul(a, b):
         return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
