@@ -37,7 +37,7 @@ class ResidentTracker:
         self.cur_slot = 1           # slots 1 / 2 alternate as "current frame"
         self._pyr_ready = None      # event: pyramid of the frame to track next is built
         self._trk_done = {1: None, 2: None}  # event per slot: last tracking kernel that read it
-        self._graph = None          # captured [pyramid -> PatchMatch] of step(graph=True)
+        self._graph = None          # graph ids of the captured step (mode "graph": one, mode "fork": two)
         self.n = 0
 
     def close(self):
@@ -124,7 +124,7 @@ class ResidentTracker:
         """One pass of the hot path over this rank's shard (+ the result all-gather): pyramid of the
         current frame, then PatchMatch.  `mode` only chooses how the two launches reach the GPU; every
         mode builds exactly one pyramid and runs one tracking launch per step (measured on MI355X,
-        752x480 / 1000 features, tools/graph_fork.py, profiles/r01_step_modes.log):
+        752x480 / 1000 features, tools/step_modes.py, profiles/r01_step_modes.log):
           "graph"   (default) one hipGraphLaunch replaying [pyramid -> PatchMatch], captured on first use
                     (BASELINE configs[4]: "hipGraph-captured iterate"): no inter-launch gap, 121.7 us;
           "serial"  the same two launches issued directly on one stream: 132.9 us (5 us gap per launch);

@@ -3,7 +3,6 @@ committed golden vectors.  Bar (BASELINE.json north_star): status masks bit-exac
 coordinates within 1e-3 px.  The kernels reproduce the CPU arithmetic operation for operation,
 so these tests also assert bit-identical outputs (exact=True); if a future kernel trades that
 for speed, relax `exact` here -- never PT_TOL."""
-import ctypes as C
 
 import numpy as np
 import pytest

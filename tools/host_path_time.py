@@ -1,7 +1,6 @@
 """Times the literal drop-in call pagk_track() on host buffers (PCIe-inclusive).  Usage: python tools/host_path_time.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
 for cfg, n in ((1, 1000), (3, 20000)):
     w = synth.config(cfg, n=n)

@@ -1,8 +1,8 @@
-"""Times step() variants: streams+events, linear graph, fork graph.  Usage: python tools/graph_fork.py"""
+"""Times step() variants: streams+events, linear graph, fork graph.  Usage: python tools/step_modes.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, runtime, synth, distributed
+import torch
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, runtime, synth
 w = synth.config(1, n=1000)
 p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro, camera=w.camera)
 for mode in ("streams", "serial", "graph", "fork"):
