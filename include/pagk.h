@@ -156,8 +156,11 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  *   - 2-wave workgroup per feature, ordered accumulation as a v_mfma_f64_4x4x4f64 chain  (= 2)
  *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; highest throughput, >= ~10000 features)
  * 1 = reference-shaped one-thread-per-feature kernel (debug / cross-check).  2 and 3 force a variant
- * (half_patch 5, 7 or 10; other sizes fall back to the 4-wave kernel).  Every variant produces
- * bit-identical results. */
+ * (half_patch 5, 7 or 10; other sizes fall back to the 4-wave kernel).  Every variant 0-3 produces
+ * bit-identical results.
+ * 4 = EXPERIMENT, never chosen automatically: the 4-wave kernel with the reference's summation order
+ *     given up (strided partial sums + tree instead of the 441-step ordered chains).  Not parity-exact:
+ *     it exists to measure what the ordered accumulation costs. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 
 /* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,

@@ -296,6 +296,18 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_wave<4, 1>);    // P = 225
             else if (a.half == 10) e = launch(k_track_wave<7, 25>);  // P = 441
             HIPCHK(ctx, e);
+        } else if (ctx->kernel == 4 && mfma_ok) {
+            // relaxed-order experiment (NOT parity-exact; never chosen automatically)
+            const size_t lds = track_block_lds_bytes(a.half);
+            auto launch = [&](auto kern) -> hipError_t {
+                hipLaunchKernelGGL(kern, dim3(n), dim3(kBlock), lds, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e = hipErrorInvalidValue;
+            if (a.half == 5) e = launch(k_track_block<1, 25, 4, false, true>);
+            else if (a.half == 7) e = launch(k_track_block<1, 1, 4, false, true>);
+            else if (a.half == 10) e = launch(k_track_block<2, 25, 4, false, true>);
+            HIPCHK(ctx, e);
         } else if (use_mfma) {
             const size_t lds = track_mfma_lds_bytes(a.half);
             auto launch = [&](auto kern) -> hipError_t {
@@ -575,7 +587,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
 
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
-    if (!ctx || which < 0 || which > 3) return PAGK_E_ARG;
+    if (!ctx || which < 0 || which > 4) return PAGK_E_ARG;
     ctx->kernel = which;
     return PAGK_OK;
 }

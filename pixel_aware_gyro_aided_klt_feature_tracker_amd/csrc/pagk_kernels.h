@@ -423,10 +423,66 @@ __device__ __forceinline__ uint32_t lds_off(const void *p)
     return (uint32_t)(uintptr_t)p;  // low half of a flat LDS address = offset in the LDS aperture
 }
 
-template <int NR, int TAIL, int WAVES = 4, bool MFMA = false>
+// ---- relaxed-order accumulation (EXPERIMENT, pagk_set_kernel(ctx, 4)) -----------------------------
+// What the reference's summation order costs: the same kernel with the 441-step ordered chains replaced by
+// per-lane strided partial sums and a 16-lane tree.  NOT parity-exact -- H is structurally singular, so a
+// different rounding of H and b moves a few percent of the features by more than the 1e-3 px bar (SURVEY.md
+// section 0; measured in tests/test_parity_gpu.py::test_relaxed_order_experiment) -- and therefore never
+// selected automatically and never the benchmark's `value`.
+template <int N>
+__device__ __forceinline__ double row_shr_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, false);  // row_shr:N, lanes without a source get 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ float row_shr_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, false));
+}
+// sum of arr[0..P) * s1 over the 16 lanes of a DPP row; the total lands in lane 15 of the row
+__device__ __forceinline__ double relaxed_row_f64(const double *arr, int P, int lr, double s1)
+{
+    double s0 = 0.0, s1a = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = lr;
+    for (; k + 48 < P; k += 64) {
+        s0 = __builtin_fma(arr[k], s1, s0);
+        s1a = __builtin_fma(arr[k + 16], s1, s1a);
+        s2 = __builtin_fma(arr[k + 32], s1, s2);
+        s3 = __builtin_fma(arr[k + 48], s1, s3);
+    }
+    for (; k < P; k += 16) s0 = __builtin_fma(arr[k], s1, s0);
+    double s = (s0 + s1a) + (s2 + s3);
+    s += row_shr_f64<8>(s);
+    s += row_shr_f64<4>(s);
+    s += row_shr_f64<2>(s);
+    s += row_shr_f64<1>(s);
+    return s;
+}
+__device__ __forceinline__ float relaxed_row_f32(const float *arr, int P, int lr)
+{
+    float s0 = 0.0f, s1 = 0.0f;
+    int k = lr;
+    for (; k + 16 < P; k += 32) {
+        s0 += arr[k];
+        s1 += arr[k + 16];
+    }
+    for (; k < P; k += 16) s0 += arr[k];
+    float s = s0 + s1;
+    s += row_shr_f32<8>(s);
+    s += row_shr_f32<4>(s);
+    s += row_shr_f32<2>(s);
+    s += row_shr_f32<1>(s);
+    return s;
+}
+
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
 __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackArgs a)
 {
     static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
+    static_assert(!(MFMA && RELAXED), "the relaxed-order experiment exists for the 4-wave kernel only");
     constexpr int kBlock = WAVES * 64;
     constexpr int kStreams = MFMA ? 3 : 8;
     constexpr int kAcc = MFMA ? 24 : 16;
@@ -671,6 +727,16 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
                 } else {
                     float c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
                     if (lane == 0) sh_cost[0] = c;
+                }
+            } else if constexpr (RELAXED) {
+                if (wave < 3) {
+                    // H22 = sum of c * c: the row re-reads one constant, so its sum is P * c * c
+                    double s = cid < 11 ? relaxed_row_f64(stream + (size_t)stream_of[cid] * PP, P, lr, row_s1)
+                                        : (double)P * cd * cd;
+                    if (lr == 15) acc[cid] = s;
+                } else {
+                    float c = relaxed_row_f32(esq, P, lr);
+                    if (lane == 15) sh_cost[0] = c;
                 }
             } else if (wave < 3) {
                 double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);

@@ -495,3 +495,23 @@ def test_randomized_parity_sweep(ctx, seed):
         what = (f"seed {seed} kernel {kernel}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} n={w.n} h={w.half_patch} "
                 f"L={w.pyramids} it={w.iterations} {flags}")
         assert_parity(got, ref, w.n, exact=True, what=what)
+
+
+def test_relaxed_order_experiment(ctx):
+    # pagk_set_kernel(ctx, 4): the summation order of H, b and cost given up.  NOT the product path -- this test
+    # records what that does to parity (H is structurally singular, so rounding differences reach dg/db and the
+    # convergence test): statuses may flip and a few percent of the points move past the 1e-3 px bar.
+    w = synth.config(1, n=2000)
+    p = params_for(w)
+    got, ref = run_both(ctx, p, w, kernel=4)
+    n = w.n
+    both = (got["status"][:n] == 1) & (ref["status"][:n] == 1)
+    d = np.abs(got["pt_un"][:n].astype(np.float64) - ref["pt_un"][:n].astype(np.float64)).max(axis=1)
+    flips = int((got["status"][:n] != ref["status"][:n]).sum())
+    off = float((d[both] > 1e-3).mean())
+    print(f"relaxed order: status flips {flips}/{n}, {100*off:.2f}% of tracked points off by > 1e-3 px, "
+          f"max {d[both].max():.3g} px, median {np.median(d[both]):.3g} px")
+    # measured on MI355X: 0 flips, 28-30 % of the points beyond 1e-3 px, max 0.2-0.8 px (profiles/r01_relaxed_order.log)
+    assert flips <= 0.02 * n                       # it is still the same optimisation ...
+    assert np.median(d[both]) < 1e-2 and d[both].max() < 5.0
+    assert off > 0.01                              # ... but far outside the parity bar: this mode can never be the product
