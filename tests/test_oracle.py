@@ -165,3 +165,18 @@ def test_odd_sized_pyramid_levels(built):
     p = capi.make_params(half_patch=5, iterations=10, pyramids=3, camera=w.camera)
     out = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
     assert out["status"][:40].sum() > 25
+
+
+def test_oracle_under_address_and_ub_sanitizers(built, tmp_path):
+    # CPU-only (GPU ASan does not exist on the pool): tests/asan_driver.c drives every oracle entry point over
+    # odd sizes, padded rows, border / far-outside / NaN coordinates; any report aborts with a non-zero exit
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "asan_driver")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-fno-omit-frame-pointer", "-std=c11", "-ffp-contract=off", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(root, "oracle"), os.path.join(root, "tests", "asan_driver.c"),
+                    os.path.join(root, "oracle", "pagk_oracle.c"), "-o", exe, "-lm", "-lpthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "asan driver ok" in r.stdout, r.stderr[-2000:]
