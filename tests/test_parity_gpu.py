@@ -515,3 +515,28 @@ def test_relaxed_order_experiment(ctx):
     assert flips <= 0.02 * n                       # it is still the same optimisation ...
     assert np.median(d[both]) < 1e-2 and d[both].max() < 5.0
     assert off > 0.01                              # ... but far outside the parity bar: this mode can never be the product
+
+
+def test_two_contexts_on_two_host_threads(built):
+    # a pagk_ctx is single-owner (reference: one PatchMatch per tracker thread, :99 shared mLevel); two contexts
+    # driven from two host threads at once must not disturb each other
+    import threading
+    ws = [synth.config(1, n=700), synth.config(2, n=500)]
+    refs, errs = [], []
+    for w in ws:
+        refs.append(orc.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8))
+
+    def worker(k):
+        try:
+            w, c = ws[k], capi.Context(0)
+            p = params_for(w)
+            for _ in range(15):
+                got = c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+                assert_parity(got, refs[k], w.n, exact=True, what=f"thread {k}")
+            c.close()
+        except Exception as e:   # surfaced in the main thread
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
