@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
                 }
             }
             __syncthreads();
+            __builtin_amdgcn_s_setprio(3);  // chain + solve first (see k_track_block); -2 % at 20000 features
             // ---- 2. H and b: ordered MFMA chain -------------------------------------------------
             {
                 constexpr int kU = 4;
@@ -242,6 +243,7 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
                 }
             }
             __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
             // ---- 5. update + termination (:322-344) -----------------------------------------------
             const double u0 = sh_upd[0], u1 = sh_upd[1], u2 = sh_upd[2], u3 = sh_upd[3], unorm = sh_upd[4];
             const float cost = sh_cost[1];
