@@ -1,0 +1,32 @@
+"""One-off soak: the randomized parity sweep of tests/test_parity_gpu.py over many more seeds.
+Usage: python tools/soak.py [first_seed] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from oracle import pagk_oracle as orc
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi
+import test_parity_gpu as T
+from util import assert_parity
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 300
+ctx = capi.Context(0)
+bad = 0
+feats = 0
+for seed in range(first, first + count):
+    w, flags = T._random_case(seed)
+    p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
+                         camera=w.camera, **flags)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
+    for kernel in (0, 2, 3):
+        ctx.set_kernel(kernel)
+        got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        try:
+            assert_parity(got, ref, w.n, exact=True, what=f"seed {seed} kernel {kernel}")
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+    feats += w.n
+    if (seed - first) % 50 == 49:
+        print(f"{seed - first + 1} cases, {feats} features, {bad} mismatches", flush=True)
+ctx.set_kernel(0)
+print(f"soak done: {count} cases x 3 kernels, {feats} features, {bad} mismatches")
