@@ -1,6 +1,6 @@
 """Row f4: the text formats of the reference's demo, parsed by csrc/host/sequence_io.cpp.  The keypoint lists
 and corresponds.txt under tests/golden/seq/ are data files taken from the reference's own
-Examples/Demo/data/PKUSZ_RealSenseD435i_sequence/SuperPoints.zip (first three frames, first twelve
+Examples/Demo/data/PKUSZ_RealSenseD435i_sequence/SuperPoints.zip (first four frames, first twelve
 correspondences); imu.txt / image_file_list.txt are not shipped with the reference (its sequence_1.zip is
 listed in .MISSING_LARGE_BLOBS), so those two are written here in the format its readers parse."""
 import os
@@ -13,6 +13,7 @@ from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, host_api, synth
 
 SEQ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq")
 STAMPS = ["1627889784040685824", "1627889784107402752", "1627889784174119936"]
+STAMP4 = "1627889784240837120"   # a fourth list, only used to reach the 2000 keypoints of BASELINE configs[2]
 
 
 def test_keypoint_lists_of_the_reference(built):
@@ -110,4 +111,33 @@ def test_replay_real_keypoints_through_the_tracker(built):
                 assert np.array_equal(got[k][:500], ref[k][:500], equal_nan=True), (s, k)
             assert got["status"][:500].sum() > 300
     finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_baseline_config2_shape_with_superpoint_keypoints(built):
+    # BASELINE configs[2]: 640x480, 2000 keypoints "SuperPoint-loaded", 21x21 patch, 4 levels -- the keypoints are
+    # the reference's own lists (4 frames x 500), the image pair is the synthetic D435i-like stand-in
+    kp = np.concatenate([host_api.load_keypoints(os.path.join(SEQ, s + ".txt")) for s in STAMPS + [STAMP4]])
+    assert kp.shape == (2000, 2)
+    w = synth.config(2, n=2000)                       # 640x480, L = 4, D435i intrinsics
+    p = capi.make_params(half_patch=10, iterations=30, pyramids=4, has_gyro=True, camera=synth.D435I)
+    Rp = synth.rodrigues(np.array((0.004, -0.003, 0.006))) @ synth.rodrigues(np.array((0.3, -0.5, 1.0)) * 0.05)
+    K32 = synth.D435I.K.astype(np.float32)
+
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    KRK = mul(mul(K32, Rp.astype(np.float32)), np.linalg.inv(K32.astype(np.float64)).astype(np.float32))
+    pu, pd, st, A = orc.gyro_predict(p, 640, 480, 10, KRK, Rp.astype(np.float32)[2], kp)
+    ctx = capi.Context(0)
+    try:
+        for kernel in (0, 2, 3):
+            ctx.set_kernel(kernel)
+            got = ctx.track(p, w.img_ref, w.img_cur, kp, pu, A, st)
+            ref = orc.track(p, w.img_ref, w.img_cur, kp, pu, A, st, nthreads=16)
+            for k in ("status", "pt_un", "pt_dist", "pix_err", "dist_pred", "iters"):
+                assert np.array_equal(got[k][:2000], ref[k][:2000], equal_nan=True), (kernel, k)
+        assert 1500 < int(st.sum()) <= 2000 and got["status"][:2000].sum() > 1200
+    finally:
+        ctx.set_kernel(0)
         ctx.close()
