@@ -179,6 +179,12 @@ int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms);
 int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
                              const float *KRKinv, const float *r3, int32_t n, const float *d_pt_ref_un,
                              float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status, float *d_affine);
+/* The same with the rotation in DEVICE memory: d_rot = 9 floats, rows 0 and 1 of KRKinv followed by r3.
+ * For graph capture: kernel arguments are frozen into a captured graph, device memory is not, so a graph
+ * holding upload -> pyramid -> prediction -> tracking replays every frame with that frame's rotation. */
+int pagk_gyro_predict_device_rot(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                                 const float *d_rot, int32_t n, const float *d_pt_ref_un, float *d_pt_predict_un,
+                                 float *d_pt_predict, uint8_t *d_status, float *d_affine);
 
 /* Tracker-side post-filter, GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined
  * Step 3 (src/gyro_aided_tracker.cpp:289-341): thresholds from the mean pixel
@@ -191,7 +197,7 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
 
 /* hipGraph capture of the per-frame work (BASELINE configs[4], "hipGraph-captured iterate").  A camera
  * stream issues the same launches on the same device pointers every frame; between pagk_graph_begin and
- * pagk_graph_end the *_device entry points (pagk_frame_set_device, pagk_gyro_predict_device,
+ * pagk_graph_end the *_device entry points (pagk_frame_set_device, pagk_gyro_predict_device[_rot],
  * pagk_track_device, pagk_geometry_scores_device) are recorded on the context stream instead of executed,
  * pagk_graph_launch replays them with one hipGraphLaunch.  Rules: run the same calls once before capturing
  * (nothing may allocate during capture); host-buffer and synchronising entry points return PAGK_E_ARG while

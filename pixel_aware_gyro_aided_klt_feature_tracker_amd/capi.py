@@ -155,6 +155,8 @@ def declare(lib) -> None:
     lib.pagk_last_kernel_ms.argtypes = [vp, _P(C.c_float), _P(C.c_float)]
     lib.pagk_gyro_predict_device.restype = C.c_int
     lib.pagk_gyro_predict_device.argtypes = [vp, _P(Params), i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.pagk_gyro_predict_device_rot.restype = C.c_int
+    lib.pagk_gyro_predict_device_rot.argtypes = [vp, _P(Params), i32, i32, vp, i32, vp, vp, vp, vp, vp]
     lib.pagk_post_filter.restype = C.c_int
     lib.pagk_post_filter.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     f32 = C.c_float
@@ -182,6 +184,7 @@ EXPORTED_SYMBOLS = [
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
     "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
+    "pagk_gyro_predict_device_rot",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
     "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
 ]
@@ -334,6 +337,14 @@ class Context:
         if rc < 0:
             self._check(rc, "pagk_geometry_validation")
         return rc, st, np.float32(ts.value)
+
+    def gyro_predict_device_rot(self, params: Params, width: int, height: int, d_rot, n: int, d_pt_ref,
+                                d_pt_predict_un, d_pt_predict, d_status, d_affine):
+        """Prediction with the rotation (KRKinv rows 0-1, r3: 9 floats) in device memory: capturable per frame."""
+        self._check(self.lib.pagk_gyro_predict_device_rot(self.h, C.byref(params), width, height, _ptr(d_rot), n,
+                                                          _ptr(d_pt_ref), _ptr(d_pt_predict_un), _ptr(d_pt_predict),
+                                                          _ptr(d_status), _ptr(d_affine)),
+                    "pagk_gyro_predict_device_rot")
 
     # hipGraph capture of the *_device calls issued on the context stream --------------------
     def graph_begin(self):

@@ -773,11 +773,12 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
                              ctx->slots[5]);
 }
 
-int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
-                             const float *KRKinv, const float *r3, int32_t n, const float *d_pt_ref_un,
-                             float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status, float *d_affine)
+static int gyro_predict_any(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                            const float *KRKinv, const float *r3, const float *d_rot, int32_t n,
+                            const float *d_pt_ref_un, float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status,
+                            float *d_affine)
 {
-    if (!ctx || !params || !KRKinv || !r3 || n < 0 || width < 1 || height < 1) return PAGK_E_ARG;
+    if (!ctx || !params || (!d_rot && (!KRKinv || !r3)) || n < 0 || width < 1 || height < 1) return PAGK_E_ARG;
     if (params->half_patch < 1 || params->half_patch > PAGK_MAX_HALF_PATCH) return PAGK_E_ARG;
     if (n > 0 && (!d_pt_ref_un || !d_pt_predict_un || !d_pt_predict || !d_status)) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -790,8 +791,12 @@ int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t w
     a.fy_inv = (float)(1.0 / (double)params->fy);
     a.k1 = params->dist_coef[0], a.k2 = params->dist_coef[1], a.p1 = params->dist_coef[2], a.p2 = params->dist_coef[3];
     a.k3 = params->n_dist_coef == 5 ? params->dist_coef[4] : 0.0f;
-    for (int k = 0; k < 6; k++) a.K[k] = KRKinv[k];
-    a.r31 = r3[0], a.r32 = r3[1], a.r33 = r3[2];
+    if (d_rot) {
+        a.d_rot = d_rot;
+    } else {
+        for (int k = 0; k < 6; k++) a.K[k] = KRKinv[k];
+        a.r31 = r3[0], a.r32 = r3[1], a.r33 = r3[2];
+    }
     // (B B^T)^-1 for B = +-h corners (:73-78): B B^T = diag(4h^2); cv::Mat::inv of a 2x2 goes through
     // the double determinant
     const float m00 = 4.0f * a.half * a.half;
@@ -808,6 +813,23 @@ int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t w
         HIPCHK(ctx, hipGetLastError());
     }
     return PAGK_OK;
+}
+
+int pagk_gyro_predict_device(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                             const float *KRKinv, const float *r3, int32_t n, const float *d_pt_ref_un,
+                             float *d_pt_predict_un, float *d_pt_predict, uint8_t *d_status, float *d_affine)
+{
+    return gyro_predict_any(ctx, params, width, height, KRKinv, r3, nullptr, n, d_pt_ref_un, d_pt_predict_un,
+                            d_pt_predict, d_status, d_affine);
+}
+
+int pagk_gyro_predict_device_rot(pagk_ctx *ctx, const pagk_params *params, int32_t width, int32_t height,
+                                 const float *d_rot, int32_t n, const float *d_pt_ref_un, float *d_pt_predict_un,
+                                 float *d_pt_predict, uint8_t *d_status, float *d_affine)
+{
+    if (!d_rot) return PAGK_E_ARG;
+    return gyro_predict_any(ctx, params, width, height, nullptr, nullptr, d_rot, n, d_pt_ref_un, d_pt_predict_un,
+                            d_pt_predict, d_status, d_affine);
 }
 
 // GyroAidedTracker::GyroPredictFeaturesAndOpticalFlowRefined, Step 3,

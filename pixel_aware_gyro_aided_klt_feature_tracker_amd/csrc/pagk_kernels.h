@@ -163,6 +163,9 @@ struct PredictArgs {
     const float *pt_ref;
     float *pt_un, *pt_dist, *affine;
     uint8_t *status;
+    // when non-null: 9 floats on the device, rows 0 and 1 of mKRKinv then the third row of mRcl; they replace
+    // K[] and r31..r33 above (the rotation of a captured graph must not be baked into its kernel arguments)
+    const float *d_rot;
 };
 
 // GyroPredictOnePixel, PIXEL_AWARE_PREDICTION (:205-231)
@@ -191,6 +194,10 @@ __global__ void __launch_bounds__(256) k_gyro_predict(PredictArgs a)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    if (a.d_rot) {
+        for (int k = 0; k < 6; k++) a.K[k] = a.d_rot[k];
+        a.r31 = a.d_rot[6], a.r32 = a.d_rot[7], a.r33 = a.d_rot[8];
+    }
     // Initialize() state where the loop `continue`s (:92-95, :131-135)
     a.status[i] = 0;
     a.pt_un[2 * i] = a.pt_un[2 * i + 1] = 0.0f;

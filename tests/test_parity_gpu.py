@@ -540,3 +540,67 @@ def test_two_contexts_on_two_host_threads(built):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_whole_frame_as_one_graph(ctx):
+    # new frame (device-to-device copy into the fixed buffer) -> pyramid -> gyro prediction (rotation read from
+    # device memory) -> PatchMatch, captured once; every replay must use that frame's pixels and rotation
+    cam = synth.EUROC
+    w = synth.config(1, n=800, edge_fraction=0.1)
+    p = params_for(w)
+    K32 = cam.K.astype(np.float32)
+    Kinv32 = np.linalg.inv(K32.astype(np.float64)).astype(np.float32)
+
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+
+    def rot9(R):
+        R32 = R.astype(np.float32)
+        KRK = mul(mul(K32, R32), Kinv32)
+        return KRK, R32[2], np.concatenate([KRK.reshape(-1)[:6], R32[2]]).astype(np.float32)
+    Ra = synth.rodrigues(np.array((0.004, -0.003, 0.006))) @ synth.rodrigues(np.array((0.5, -1.0, 2.0)) * 0.05)
+    Rb = synth.rodrigues(np.array((0.5, -1.0, 2.0)) * 0.05)
+    frames = [(w.img_cur, Ra), (w.img_ref, np.eye(3)), (w.img_cur, Rb)]   # (current image, predicted rotation)
+    stream = torch.cuda.Stream()
+    c = capi.Context(0)
+    try:
+        with torch.cuda.stream(stream):
+            n, dev = w.n, torch.device("cuda", 0)
+            d_cur = torch.zeros((480, 752), dtype=torch.uint8, device=dev)      # the camera's fixed device buffer
+            d_new = [torch.from_numpy(np.ascontiguousarray(f[0])).to(dev) for f in frames]
+            d_rots = [torch.from_numpy(rot9(f[1])[2]).to(dev) for f in frames]
+            d_rot = torch.zeros(9, dtype=torch.float32, device=dev)
+            d_ref = torch.from_numpy(w.pt_ref).to(dev)
+            d_pu, d_pd = torch.zeros((n, 2), device=dev), torch.zeros((n, 2), device=dev)
+            d_st, d_A = torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros((n, 4), device=dev)
+            out = distributed.alloc_device_outputs(n, dev)
+            c.set_stream(stream.cuda_stream)
+            c.frame_upload(0, w.img_ref, p.pyramids)                             # reference frame, resident
+            stream.synchronize()
+
+            def frame_work():
+                c.frame_set_device(1, d_cur.data_ptr(), 752, 480, 752, p.pyramids)
+                c.gyro_predict_device_rot(p, 752, 480, d_rot, n, d_ref, d_pu, d_pd, d_st, d_A)
+                c.track_device(p, 0, 1, n, d_ref, d_pu, d_A, d_st, out)
+            frame_work()                                                         # warm-up (allocations)
+            stream.synchronize()
+            c.graph_begin()
+            try:
+                frame_work()
+            finally:
+                gid = c.graph_end()
+            for k, (img, R) in enumerate(frames):
+                d_cur.copy_(d_new[k])                                            # "camera DMA" into the fixed buffer
+                d_rot.copy_(d_rots[k])
+                c.graph_launch(gid)
+                stream.synchronize()
+                KRK, r3, _ = rot9(R)
+                pu, pd, st, A = orc.gyro_predict(p, 752, 480, w.half_patch, KRK, r3, w.pt_ref)
+                ref = orc.track(p, w.img_ref, img, w.pt_ref, pu, A, st, nthreads=16)
+                assert np.array_equal(d_st.cpu().numpy(), st) and np.array_equal(d_pu.cpu().numpy(), pu)
+                got = {kk: out[kk].cpu().numpy() for kk, _, _ in distributed.FIELDS}
+                assert_parity(got, ref, n, exact=True, what=f"whole-frame graph, replay {k}")
+            c.graph_destroy(gid)
+    finally:
+        c.set_stream(None)
+        c.close()
