@@ -225,7 +225,9 @@ def main() -> int:
                                    "(synthetic stand-in for BASELINE configs[1])",
                        "features_total": n_total, "features_active": n_active_total,
                        "sharding": f"contiguous feature blocks x{world} + all-gather" if world > 1 else "none",
-                       "step": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch"
+                       "step": "pyramid(current frame) -> PatchMatch(all features), "
+                               + ("replayed as one hipGraph launch" if rt.mode_used == "graph" else
+                                  f"issued as direct launches ({rt.mode_used})")
                                + (" + all-gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

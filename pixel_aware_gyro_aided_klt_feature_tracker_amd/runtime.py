@@ -38,6 +38,8 @@ class ResidentTracker:
         self._pyr_ready = None      # event: pyramid of the frame to track next is built
         self._trk_done = {1: None, 2: None}  # event per slot: last tracking kernel that read it
         self._graph = None          # graph ids of the captured step (mode "graph": one, mode "fork": two)
+        self._graph_failed = False  # capture was refused once: direct launches from then on
+        self.mode_used = "serial"   # how the last step's launches were issued
         self.n = 0
 
     def close(self):
@@ -136,12 +138,29 @@ class ResidentTracker:
         if mode not in ("graph", "fork", "serial", "streams"):
             raise ValueError(mode)
         with torch.cuda.stream(self.main):
-            if graph:
-                self._graph_step(fork=(graph == "fork"))
+            if graph and not self._graph_failed:
+                try:
+                    self._graph_step(fork=(graph == "fork"))
+                except capi.PagkError as e:
+                    # capture refused by the runtime (never seen on MI355X / ROCm 7.2): keep going with the same two
+                    # launches issued directly -- still the HIP path -- and say so
+                    import sys
+                    print(f"pagk: hipGraph capture failed ({e}); step() falls back to direct launches", file=sys.stderr)
+                    self._graph_failed, self._graph = True, None
+                    self.ctx.set_stream(self.main.cuda_stream)
+                    self.rebuild_current_pyramid(1)
+                    self.track_shard(1)
+                else:
+                    self.mode_used = mode
+            elif graph:
+                self.rebuild_current_pyramid(1)
+                self.track_shard(1)
             elif not overlap:
+                self.mode_used = "serial"
                 self.rebuild_current_pyramid(1)
                 self.track_shard(1)
             else:
+                self.mode_used = "streams"
                 if self._pyr_ready is None:                       # first step: nothing prefetched yet
                     self._pyr_ready = self._prefetch_pyramid(self.cur_slot)
                 self.main.wait_event(self._pyr_ready)
