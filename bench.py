@@ -114,18 +114,23 @@ def main() -> int:
     n_active_total = w.n_active
     n_active_local = int(np.count_nonzero(w.status_in[rt.lo:rt.hi]))
 
+    # how a step's launches reach the GPU (runtime.ResidentTracker.step): "fused" = PatchMatch of the pair and the
+    # pyramid of the following frame in ONE launch, replayed as a single-node hipGraph; "graph" = pyramid then
+    # PatchMatch as a two-node graph (valid for a live camera with no frame of look-ahead)
+    step_mode = os.environ.get("PAGK_STEP_MODE", "fused")
+
     def barrier():
         if world > 1:
             dist.barrier()
 
     for _ in range(args.warmup):
-        out = rt.step()
+        out = rt.step(mode=step_mode)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = rt.step()
+        out = rt.step(mode=step_mode)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -180,21 +185,21 @@ def main() -> int:
             for _ in range(k):
                 for r2 in cams:
                     r2.step(**kw)
-        cam_steps(5)
+        cam_steps(5, mode=step_mode)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ksteps = max(20, args.steps // 2)
-        cam_steps(ksteps)
+        cam_steps(ksteps, mode=step_mode)
         torch.cuda.synchronize()
         tc = time.perf_counter() - t1
         extras["multi_camera"] = {"value": n_active_total * C * ksteps / tc, "unit": "features/s", "cameras": C,
                                   "steps_per_camera": ksteps,
-                                  "what": f"{C} independent cameras (one hipGraph replay per camera and frame) in "
+                                  "what": f"{C} independent cameras (one hipGraph replay per camera and frame, mode {step_mode}) in "
                                           "flight on one GPU"}
         # (c) how the step's two launches reach the GPU (runtime.ResidentTracker.step modes), one camera:
         #     `value` uses "graph" (one hipGraphLaunch replaying [pyramid -> PatchMatch])
         modes = {}
-        for m in ("graph", "serial", "streams"):
+        for m in ("fused", "graph", "serial", "streams"):
             for _ in range(5):
                 cams[0].step(mode=m)
             torch.cuda.synchronize()
@@ -225,10 +230,12 @@ def main() -> int:
                                    "(synthetic stand-in for BASELINE configs[1])",
                        "features_total": n_total, "features_active": n_active_total,
                        "sharding": f"contiguous feature blocks x{world} + all-gather" if world > 1 else "none",
-                       "step": "pyramid(current frame) -> PatchMatch(all features), "
-                               + ("replayed as one hipGraph launch" if rt.mode_used == "graph" else
-                                  f"issued as direct launches ({rt.mode_used})")
-                               + (" + all-gather" if world > 1 else "")},
+                       "step": {"fused": "PatchMatch(all features of the pair) + pyramid(next frame) in ONE launch (trailing "
+                                         "workgroups), replayed as a single-node hipGraph",
+                                "graph": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch"
+                                }.get(rt.mode_used, f"pyramid + PatchMatch issued as direct launches ({rt.mode_used})")
+                               + (" + all-gather" if world > 1 else ""),
+                       "step_mode": rt.mode_used},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": (f"profiles/{traffic_tag}/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB "

@@ -146,6 +146,16 @@ int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref
                       int32_t slot_cur, int32_t n, const float *d_pt_ref_un,
                       const float *d_pt_init_un, const float *d_affine,
                       const uint8_t *d_status_in, const pagk_outputs *d_out);
+/* pagk_track_device for the pair (slot_ref, slot_cur) AND CreatePyramids (src/patch_match.cpp:61-76) of another
+ * frame -- device image d_next, built into slot_next -- in ONE launch: when the 4-wave kernel is the one
+ * selected, the pyramid is computed by trailing workgroups of the tracking launch and costs no launch of its
+ * own; otherwise it is launched separately.  Results are those of pagk_frame_set_device(slot_next, ...) plus
+ * pagk_track_device(...).  For pipelines that hold frame k+1 while pair (k-1, k) is tracked (replays, or a
+ * camera loop that accepts one frame of latency).  slot_next must differ from slot_ref and slot_cur. */
+int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref, int32_t slot_cur, int32_t n,
+                            const float *d_pt_ref_un, const float *d_pt_init_un, const float *d_affine,
+                            const uint8_t *d_status_in, const pagk_outputs *d_out, int32_t slot_next,
+                            const void *d_next, int32_t width, int32_t height, int64_t step, int32_t pyramids);
 int pagk_sync(pagk_ctx *ctx);
 /* Use an external HIP stream (e.g. torch's current stream) instead of the
  * context's own; pass NULL to restore. */

@@ -145,6 +145,9 @@ def declare(lib) -> None:
     lib.pagk_frame_download_level.argtypes = [vp, i32, i32, vp, _P(i32), _P(i32)]
     lib.pagk_track_device.restype = C.c_int
     lib.pagk_track_device.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs)]
+    lib.pagk_track_device_fused.restype = C.c_int
+    lib.pagk_track_device_fused.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs), i32, vp, i32, i32,
+                                            C.c_int64, i32]
     lib.pagk_sync.restype = C.c_int
     lib.pagk_sync.argtypes = [vp]
     lib.pagk_set_stream.restype = C.c_int
@@ -182,7 +185,7 @@ def declare(lib) -> None:
 EXPORTED_SYMBOLS = [
     "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
-    "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_sync",
+    "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_track_device_fused", "pagk_sync",
     "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
     "pagk_gyro_predict_device_rot",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
@@ -281,6 +284,16 @@ class Context:
         self._check(self.lib.pagk_track_device(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
                                                _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o)),
                     "pagk_track_device")
+
+    def track_device_fused(self, params: Params, slot_ref: int, slot_cur: int, n: int, d_pt_ref, d_pt_init, d_affine,
+                           d_status, d_out: dict, slot_next: int, d_next_ptr: int, width: int, height: int, step: int,
+                           pyramids: int):
+        """pagk_track_device + the pyramid of another frame into slot_next, one launch when possible."""
+        o = outputs_struct(d_out)
+        self._check(self.lib.pagk_track_device_fused(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
+                                                     _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o),
+                                                     slot_next, d_next_ptr, width, height, step, pyramids),
+                    "pagk_track_device_fused")
 
     def gyro_predict_device(self, params: Params, width: int, height: int, KRKinv, r3, n: int, d_pt_ref,
                             d_pt_predict_un, d_pt_predict, d_status, d_affine):

@@ -135,6 +135,44 @@ int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
     return PAGK_OK;
 }
 
+// Arguments of the single-launch pyramid (k_pyramid_fused / the trailing blocks of k_track_block_pyr) for a
+// reserved slot with at most 4 levels and even parents; returns the number of 256-thread blocks.
+int make_pyr_args(const FrameSlot &s, const uint8_t *src0, int64_t pitch0, int wrap0, PyrArgs *out)
+{
+    int lw[kMaxLevels], lh[kMaxLevels];
+    level_dims(s.w, s.h, s.L, lw, lh);
+    PyrArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.src = src0;
+    pa.pitch = pitch0;
+    pa.wrap0 = wrap0;
+    pa.n_levels = s.L;
+    int nb = 0;
+    for (int l = 0; l < 4; l++) {
+        pa.first_block[l] = nb;
+        if (l < s.L) {
+            pa.cols[l] = lw[l];
+            pa.rows[l] = lh[l];
+            pa.u8[l] = s.u8[l];
+            pa.quad[l] = s.quad[l];
+            nb += (lw[l] * lh[l] + 255) / 256;
+        }
+    }
+    pa.first_block[4] = nb;
+    for (int l = s.L; l < 4; l++) pa.first_block[l] = nb;  // empty ranges for absent levels
+    *out = pa;
+    return nb;
+}
+
+bool pyramid_fusable(const FrameSlot &s)
+{
+    int lw[kMaxLevels], lh[kMaxLevels];
+    level_dims(s.w, s.h, s.L, lw, lh);
+    bool all_even = s.L <= 4;
+    for (int l = 0; l + 1 < s.L; l++) all_even = all_even && !(lw[l] & 1) && !(lh[l] & 1);
+    return all_even;
+}
+
 // CreatePyramids (src/patch_match.cpp:61-76) + tap packing, from a level-0 image that is
 // already on the device at (src0, pitch0).
 int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0, int wrap0)
@@ -149,24 +187,7 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     for (int l = 0; l + 1 < s.L; l++) all_even = all_even && !(lw[l] & 1) && !(lh[l] & 1);
     if (s.L <= 4 && !ctx->unfused_pyramid && all_even) {
         PyrArgs pa;
-        memset(&pa, 0, sizeof pa);
-        pa.src = src0;
-        pa.pitch = pitch0;
-        pa.wrap0 = wrap0;
-        pa.n_levels = s.L;
-        int nb = 0;
-        for (int l = 0; l < 4; l++) {
-            pa.first_block[l] = nb;
-            if (l < s.L) {
-                pa.cols[l] = lw[l];
-                pa.rows[l] = lh[l];
-                pa.u8[l] = s.u8[l];
-                pa.quad[l] = s.quad[l];
-                nb += (lw[l] * lh[l] + 255) / 256;
-            }
-        }
-        pa.first_block[4] = nb;
-        for (int l = s.L; l < 4; l++) pa.first_block[l] = nb;  // empty ranges for absent levels
+        const int nb = make_pyr_args(s, src0, pitch0, wrap0, &pa);
         hipLaunchKernelGGL(k_pyramid_fused, dim3(nb), dim3(256), 0, ctx->stream, pa);
         HIPCHK(ctx, hipGetLastError());
         if (ctx->ev_pyr[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
@@ -225,10 +246,14 @@ void fill_level(DevLevel &d, const FrameSlot &s, int l)
     d.frows_m1 = (float)(h - 1);
 }
 
+// pyr / pyr_blocks / pyr_done: optionally, another slot's pyramid to be built by trailing workgroups of the
+// tracking launch (k_track_block_pyr).  Honoured when the 4-wave kernel is the one selected; *pyr_done tells the
+// caller whether it was (otherwise the caller launches the pyramid itself).
 int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
                  const float *d_pt_ref, const float *d_pt_init, const float *d_affine, const uint8_t *d_status,
-                 const pagk_outputs *o)
+                 const pagk_outputs *o, const PyrArgs *pyr = nullptr, int pyr_blocks = 0, bool *pyr_done = nullptr)
 {
+    if (pyr_done) *pyr_done = false;
     TrackArgs a;
     memset(&a, 0, sizeof a);
     a.n_levels = p->pyramids;
@@ -339,6 +364,17 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             };
             // (NR, TAIL) for h = 1..15: P = (2h+1)^2 is an odd square, so P mod 32 is 1, 9, 17 or 25
             hipError_t e = hipErrorInvalidValue;
+            if (pyr && pyr_blocks > 0 && mfma_ok && lds <= 48 * 1024) {
+                auto launch_pyr = [&](auto kern) -> hipError_t {
+                    hipLaunchKernelGGL(kern, dim3(n + pyr_blocks), dim3(kBlock), lds, ctx->stream, a, *pyr);
+                    return hipGetLastError();
+                };
+                if (a.half == 5) e = launch_pyr(k_track_block_pyr<1, 25>);
+                else if (a.half == 7) e = launch_pyr(k_track_block_pyr<1, 1>);
+                else e = launch_pyr(k_track_block_pyr<2, 25>);
+                HIPCHK(ctx, e);
+                if (pyr_done) *pyr_done = true;
+            } else
             switch (nr * 100 + tail) {
                 case 101: e = launch(k_track_block<1, 1>); break;    // h = 7
                 case 109: e = launch(k_track_block<1, 9>); break;    // h = 1, 6
@@ -353,7 +389,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 case 401: e = launch(k_track_block<4, 1>); break;    // h = 15
                 default: break;
             }
-            HIPCHK(ctx, e);
+            if (!(pyr_done && *pyr_done)) HIPCHK(ctx, e);
         }
         HIPCHK(ctx, hipGetLastError());
     }
@@ -691,6 +727,52 @@ int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref
     if (n > 0 && params->consider_affine && !d_affine) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out);
+}
+
+// Tracking of (slot_ref, slot_cur) with the pyramid of ANOTHER frame (device image d_next) built into slot_next
+// by the same launch when the 4-wave kernel is selected; otherwise two launches.  Same results as
+// pagk_frame_set_device(slot_next, ...) followed by pagk_track_device(...).
+int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref, int32_t slot_cur, int32_t n,
+                            const float *d_pt_ref_un, const float *d_pt_init_un, const float *d_affine,
+                            const uint8_t *d_status_in, const pagk_outputs *d_out, int32_t slot_next,
+                            const void *d_next, int32_t width, int32_t height, int64_t step, int32_t pyramids)
+{
+    if (!ctx || !d_next || slot_next < 0 || slot_next >= kUserSlots || slot_next == slot_ref || slot_next == slot_cur ||
+        width < 1 || height < 1 || step < width || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS)
+        return PAGK_E_ARG;
+    if (slot_ref < 0 || slot_ref >= kUserSlots || slot_cur < 0 || slot_cur >= kUserSlots) return PAGK_E_ARG;
+    int rc = check_params(params);
+    if (rc) return rc;
+    FrameSlot &sr = ctx->slots[slot_ref], &sc = ctx->slots[slot_cur], &sn = ctx->slots[slot_next];
+    if (!sr.valid || !sc.valid || sr.w != sc.w || sr.h != sc.h || sr.L < params->pyramids || sc.L < params->pyramids)
+        return PAGK_E_ARG;
+    if (n < 0 || !d_out || !d_out->pt_un || !d_out->status) return PAGK_E_ARG;
+    if (n > 0 && (!d_pt_ref_un || !d_status_in)) return PAGK_E_ARG;
+    if (n > 0 && params->has_gyro_predict_initial && !d_pt_init_un) return PAGK_E_ARG;
+    if (n > 0 && params->consider_affine && !d_affine) return PAGK_E_ARG;
+    pagk_image probe{static_cast<const uint8_t *>(d_next), width, height, step};
+    if ((rc = check_image(&probe))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    sn.valid = false;
+    if ((rc = slot_reserve(ctx, sn, width, height, pyramids))) return rc;
+    const uint8_t *src0 = static_cast<const uint8_t *>(d_next);
+    const int wrap0 = step == width;
+    bool fused = false;
+    if (n > 0 && pyramid_fusable(sn) && !ctx->unfused_pyramid) {
+        PyrArgs pa;
+        const int nb = make_pyr_args(sn, src0, step, wrap0, &pa);
+        rc = launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out, &pa, nb, &fused);
+        if (rc) return rc;
+        if (fused) {
+            sn.wrap0 = wrap0;
+            sn.valid = true;
+            return PAGK_OK;
+        }
+    } else {
+        rc = launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out);
+        if (rc) return rc;
+    }
+    return slot_build(ctx, sn, src0, step, wrap0);  // the launch selected another variant: pyramid on its own
 }
 
 int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref, const pagk_image *cur, int32_t n,

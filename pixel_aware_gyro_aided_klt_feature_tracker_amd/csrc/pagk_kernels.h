@@ -138,18 +138,23 @@ __device__ __forceinline__ void pyr_emit(const PyrArgs &a, int idx)
     if constexpr (L > 0) a.u8[L][idx] = (uint8_t)d0;
 }
 
+// one 256-thread block of the fused pyramid (b = block index within the pyramid's own range)
+__device__ __forceinline__ void pyr_block(const PyrArgs &a, int b, int tid)
+{
+    if (b < a.first_block[1]) {
+        pyr_emit<0>(a, (b - a.first_block[0]) * 256 + tid);
+    } else if (b < a.first_block[2]) {
+        pyr_emit<1>(a, (b - a.first_block[1]) * 256 + tid);
+    } else if (b < a.first_block[3]) {
+        pyr_emit<2>(a, (b - a.first_block[2]) * 256 + tid);
+    } else if (b < a.first_block[4]) {
+        pyr_emit<3>(a, (b - a.first_block[3]) * 256 + tid);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_pyramid_fused(PyrArgs a)
 {
-    const int b = blockIdx.x;
-    if (b < a.first_block[1]) {
-        pyr_emit<0>(a, (b - a.first_block[0]) * 256 + threadIdx.x);
-    } else if (b < a.first_block[2]) {
-        pyr_emit<1>(a, (b - a.first_block[1]) * 256 + threadIdx.x);
-    } else if (b < a.first_block[3]) {
-        pyr_emit<2>(a, (b - a.first_block[2]) * 256 + threadIdx.x);
-    } else {
-        pyr_emit<3>(a, (b - a.first_block[3]) * 256 + threadIdx.x);
-    }
+    pyr_block(a, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ---- GyroPredictFeatures (src/gyro_aided_tracker.cpp:118-185,194-231), one thread per feature ----
@@ -486,7 +491,7 @@ __device__ __forceinline__ float relaxed_row_f32(const float *arr, int P, int lr
 }
 
 template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
-__global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackArgs a)
+__device__ __forceinline__ void track_block_body(const TrackArgs &a)
 {
     static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
     static_assert(!(MFMA && RELAXED), "the relaxed-order experiment exists for the 4-wave kernel only");
@@ -887,6 +892,26 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
     }
 #endif
 #undef STAMP
+}
+
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
+__global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackArgs a)
+{
+    track_block_body<NR, TAIL, WAVES, MFMA, RELAXED>(a);
+}
+
+// The 4-wave kernel with the NEXT frame's pyramid built by trailing workgroups of the same launch: blocks
+// [0, n) are features, blocks [n, n + pyramid blocks) run k_pyramid_fused's body on another frame slot.  For
+// pipelines that already hold frame k+1 while pair (k-1, k) is tracked (replays, or a camera loop that accepts
+// one frame of latency): the pyramid then costs no launch of its own and runs in the tracking launch's shadow.
+template <int NR, int TAIL>
+__global__ void __launch_bounds__(256, 1) k_track_block_pyr(TrackArgs a, PyrArgs pa)
+{
+    if ((int)blockIdx.x >= a.n) {
+        pyr_block(pa, (int)blockIdx.x - a.n, (int)threadIdx.x);
+        return;
+    }
+    track_block_body<NR, TAIL, 4, false, false>(a);
 }
 
 }  // namespace pagk

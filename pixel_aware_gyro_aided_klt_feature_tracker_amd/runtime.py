@@ -37,7 +37,7 @@ class ResidentTracker:
         self.cur_slot = 1           # slots 1 / 2 alternate as "current frame"
         self._pyr_ready = None      # event: pyramid of the frame to track next is built
         self._trk_done = {1: None, 2: None}  # event per slot: last tracking kernel that read it
-        self._graph = None          # graph ids of the captured step (mode "graph": one, mode "fork": two)
+        self._graphs = {}           # mode -> graph ids of the captured step ("graph": one; "fork", "fused": two)
         self._graph_failed = False  # capture was refused once: direct launches from then on
         self.mode_used = "serial"   # how the last step's launches were issued
         self.n = 0
@@ -63,10 +63,15 @@ class ResidentTracker:
         torch.cuda.synchronize(self.dev)
 
     def _drop_graph(self):
-        if self._graph is not None:
-            for gid in self._graph:
+        for ids in self._graphs.values():
+            for gid in ids:
                 self.ctx.graph_destroy(gid)
-            self._graph = None
+        self._graphs = {}
+
+    @property
+    def _graph(self):
+        """Graph ids of the default mode (None before its first step)."""
+        return self._graphs.get("graph")
 
     def set_features(self, pt_ref, pt_init, affine, status_in):
         """Takes the FULL feature arrays; keeps this rank's contiguous shard on the device."""
@@ -132,21 +137,25 @@ class ResidentTracker:
           "serial"  the same two launches issued directly on one stream: 132.9 us (5 us gap per launch);
           "streams" pyramid of step k+1's frame on a side stream while step k tracks, ordered by events:
                     134.6 us -- a cross-stream event wait costs more than the 7.7 us pyramid it hides;
-          "fork"    that overlap as two branches of one graph: 143.6 us."""
-        graph = {"graph": True, "fork": "fork"}.get(mode, False)
+          "fork"    that overlap as two branches of one graph: 143.6 us;
+          "fused"   the next frame's pyramid as trailing workgroups of the tracking launch itself
+                    (pagk_track_device_fused), one single-node graph per parity: the pyramid costs no launch and no
+                    gap.  Like "streams" it needs frame k+1 while pair (k-1, k) is tracked."""
+        graph = {"graph": True, "fork": "fork", "fused": "fused"}.get(mode, False)
         overlap = mode == "streams"
-        if mode not in ("graph", "fork", "serial", "streams"):
+        if mode not in ("graph", "fork", "fused", "serial", "streams"):
             raise ValueError(mode)
         with torch.cuda.stream(self.main):
             if graph and not self._graph_failed:
                 try:
-                    self._graph_step(fork=(graph == "fork"))
+                    self._graph_step(fork=(graph == "fork"), fused=(graph == "fused"))
                 except capi.PagkError as e:
                     # capture refused by the runtime (never seen on MI355X / ROCm 7.2): keep going with the same two
                     # launches issued directly -- still the HIP path -- and say so
                     import sys
                     print(f"pagk: hipGraph capture failed ({e}); step() falls back to direct launches", file=sys.stderr)
-                    self._graph_failed, self._graph = True, None
+                    self._graph_failed = True
+                    self._drop_graph()
                     self.ctx.set_stream(self.main.cuda_stream)
                     self.rebuild_current_pyramid(1)
                     self.track_shard(1)
@@ -178,24 +187,41 @@ class ResidentTracker:
                 return res
         return {name: self.out[name][:self.hi - self.lo] for name, _, _ in distributed.FIELDS}
 
-    def _graph_step(self, fork: bool):
+    def track_shard_fused(self, cur: int):
+        """PatchMatch(0, cur) and, in the same launch, the pyramid of the next frame into the other slot."""
+        self.ctx.track_device_fused(self.params, 0, cur, self.hi - self.lo, self.d_pt_ref, self.d_pt_init, self.d_affine,
+                                    self.d_status, self.out, 3 - cur, self.img_cur.data_ptr(), self.w, self.h, self.w,
+                                    self.params.pyramids)
+
+    def _graph_step(self, fork: bool, fused: bool = False):
         """Replay (capturing on first use) the step as a hipGraph.  Linear form: [pyramid(slot 1) ->
         PatchMatch(0, 1)].  Fork form: two graphs, one per parity, each [PatchMatch(0, cur) || pyramid(next)]
-        -- the side-stream prefetch of step() expressed as two independent branches of one graph."""
-        if self._graph is None:
+        -- the side-stream prefetch of step() expressed as two independent branches of one graph.  Fused form:
+        two single-node graphs, [PatchMatch(0, cur) + pyramid(next frame -> the other slot) in one launch]."""
+        key = "fused" if fused else ("fork" if fork else "graph")
+        if key not in self._graphs:
             self.rebuild_current_pyramid(1)      # warm-up: allocations, kernel attributes
             self.rebuild_current_pyramid(2)
             self.track_shard(1)
             self.main.synchronize()
-            if not fork:
+            ids = []
+            if fused:
+                self.track_shard_fused(1)        # warm-up of the fused kernel
+                self.main.synchronize()
+                for cur in (1, 2):
+                    self.ctx.graph_begin()
+                    try:
+                        self.track_shard_fused(cur)
+                    finally:
+                        ids.append(self.ctx.graph_end())
+            elif not fork:
                 self.ctx.graph_begin()
                 try:
                     self.rebuild_current_pyramid(1)
                     self.track_shard(1)
                 finally:
-                    self._graph = (self.ctx.graph_end(),)
+                    ids.append(self.ctx.graph_end())
             else:
-                ids = []
                 for cur in (1, 2):
                     self.ctx.graph_begin()       # capture starts on `main`
                     try:
@@ -212,12 +238,14 @@ class ResidentTracker:
                     finally:
                         self.ctx.set_stream(self.main.cuda_stream)
                         ids.append(self.ctx.graph_end())
-                self._graph = tuple(ids)
-                self.cur_slot = 1
-        if len(self._graph) == 1:
-            self.ctx.graph_launch(self._graph[0])
+            self._graphs[key] = tuple(ids)
+            self.cur_slot = 1
+        ids = self._graphs[key]
+        if len(ids) == 1:
+            self.ctx.graph_launch(ids[0])
         else:
-            self.ctx.graph_launch(self._graph[self.cur_slot - 1])
+            # both slots hold a valid pyramid whenever the mode changes: every parity graph leaves them so
+            self.ctx.graph_launch(ids[self.cur_slot - 1])
             self.cur_slot = 3 - self.cur_slot
 
     def synchronize(self):

@@ -604,3 +604,66 @@ def test_whole_frame_as_one_graph(ctx):
     finally:
         c.set_stream(None)
         c.close()
+
+
+@pytest.mark.parametrize("h,n", [(10, 900), (5, 700), (7, 300), (9, 200), (10, 3000)])
+def test_fused_track_and_next_pyramid(ctx, h, n):
+    # pagk_track_device_fused: tracking of (ref, cur) and the pyramid of ANOTHER frame in one launch (4-wave kernel,
+    # h in {5, 7, 10}); h = 9 and n = 3000 (MFMA variant selected) take the two-launch route.  Both must equal the
+    # separate calls: tracked outputs bit-identical, every pyramid level of the third slot equal to the oracle's.
+    w = synth.make_workload("fused", 320, 240, n, seed=0xF05ED + h, half_patch=h, iterations=20, pyramids=3,
+                            camera=synth.D435I, omega=(0.2, -0.3, 0.8))
+    p = params_for(w)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+    rng = np.random.default_rng(h)
+    nxt = rng.integers(0, 256, (240, 320), dtype=np.uint8)          # "frame k+1"
+    stream = torch.cuda.Stream()
+    c = capi.Context(0)
+    try:
+        with torch.cuda.stream(stream):
+            dev = torch.device("cuda", 0)
+            c.set_stream(stream.cuda_stream)
+            c.frame_upload(0, w.img_ref, 3)
+            c.frame_upload(1, w.img_cur, 3)
+            d_next = torch.from_numpy(nxt).to(dev)
+            d = [torch.from_numpy(x).to(dev) for x in (w.pt_ref, w.pt_init, w.affine, w.status_in)]
+            out = distributed.alloc_device_outputs(n, dev)
+            for _ in range(2):
+                c.track_device_fused(p, 0, 1, n, d[0], d[1], d[2], d[3], out, 2, d_next.data_ptr(), 320, 240, 320, 3)
+            stream.synchronize()
+            got = {k: out[k].cpu().numpy() for k, _, _ in distributed.FIELDS}
+            assert_parity(got, ref, n, exact=True, what=f"fused h={h} n={n}")
+            lvl = nxt
+            for l in range(1, 3):
+                lvl = orc.pyr_down(lvl)
+                assert np.array_equal(c.frame_download_level(2, l, 320, 240), lvl), f"next-frame pyramid level {l}"
+            # the freshly built slot is usable as the next pair's current frame
+            c.track_device(p, 1, 2, n, d[0], d[1], d[2], d[3], out)
+            stream.synchronize()
+            ref2 = orc.track(p, w.img_cur, nxt, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+            assert_parity({k: out[k].cpu().numpy() for k, _, _ in distributed.FIELDS}, ref2, n, exact=True,
+                          what="pair (cur, next) on the fused-built slot")
+            with pytest.raises(capi.PagkError):                     # the next slot must be a third one
+                c.track_device_fused(p, 0, 1, n, d[0], d[1], d[2], d[3], out, 1, d_next.data_ptr(), 320, 240, 320, 3)
+    finally:
+        c.set_stream(None)
+        c.close()
+
+
+def test_resident_tracker_step_modes_agree(ctx):
+    # every way of issuing a step (fused single launch, two-node graph, direct launches, side-stream prefetch,
+    # fork graph) produces the same bits, also when one tracker switches between them
+    w = synth.config(1, n=900)
+    p = params_for(w)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+    for mode in ("fused", "fused", "fused", "graph", "serial", "fused", "streams", "streams", "fork", "fork", "graph", "fused"):
+        rt.out["_buf"].zero_()
+        torch.cuda.synchronize()
+        out = rt.step(mode=mode)
+        rt.synchronize()
+        assert rt.mode_used == mode
+        assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what=f"step mode {mode}")
+    rt.close()

@@ -5,7 +5,7 @@ import torch
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, runtime, synth
 w = synth.config(1, n=1000)
 p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro, camera=w.camera)
-for mode in ("streams", "serial", "graph", "fork"):
+for mode in ("streams", "serial", "graph", "fork", "fused", "graph", "fused"):
     rt = runtime.ResidentTracker(p, device=0)
     rt.load_pair(w.img_ref, w.img_cur)
     rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
