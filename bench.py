@@ -50,8 +50,8 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("PAGK_CPU_THREADS", "16"))))
 
 
-def measured_traffic(workload_name: str, n: int):
-    """HBM bytes per k_track_block launch from the committed PMC profile of this workload
+def measured_traffic(workload_name: str, n: int, kernel: str = "k_track_block"):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this workload
     (profiles/<tag>/pmc_summary.json; collected by tools/profile.sh in separate --pmc passes)."""
     try:
         pdir = os.path.join(ROOT, "profiles")
@@ -62,7 +62,7 @@ def measured_traffic(workload_name: str, n: int):
             ref = json.load(f)
         if ref["config"]["workload"].split(":")[0] != workload_name or ref["config"]["features_total"] != n:
             return None, None
-        k = next(v for name, v in prof.items() if "k_track_block" in name)
+        k = next(v for name, v in prof.items() if f"::{kernel}<" in name)
         return (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0, tag
     except Exception:
         return None, None
@@ -144,14 +144,19 @@ def main() -> int:
     # library on the stream the kernel runs on (pagk_last_kernel_ms); untimed extra launches.
     trk, pyr = [], []
     torch.cuda.synchronize()
-    for _ in range(min(50, max(10, args.steps))):
-        rt.rebuild_current_pyramid(1)
-        rt.track_shard(1)
-        a, b = rt.ctx.last_kernel_ms()
-        trk.append(a)
-        pyr.append(b)
+    fused_kernel = rt.mode_used == "fused"
+    with torch.cuda.stream(rt.main):
+        for k in range(min(50, max(10, args.steps))):
+            if fused_kernel:   # the launch of the timed loop: k_track_block_pyr (tracking + next frame's pyramid)
+                rt.track_shard_fused(1 + (k & 1))
+            else:
+                rt.rebuild_current_pyramid(1)
+                rt.track_shard(1)
+            a, b = rt.ctx.last_kernel_ms()
+            trk.append(a)
+            pyr.append(b)
     kernel_ms = float(np.mean(trk))
-    pyramid_ms = float(np.mean(pyr))
+    pyramid_ms = None if fused_kernel else float(np.mean(pyr))
 
     res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
@@ -215,7 +220,8 @@ def main() -> int:
     if rank == 0:
         b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
         achieved = n_active_local * b_alg / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_tag = measured_traffic(w.name, n_total) if world == 1 else (None, None)
+        traffic, traffic_tag = (measured_traffic(w.name, n_total, "k_track_block_pyr" if fused_kernel else "k_track_block")
+                                if world == 1 else (None, None))
         line = {
             "metric": "tracked features/sec (21x21, 3-lvl, 30 iter)",
             "value": n_active_total * args.steps / elapsed,
@@ -240,10 +246,13 @@ def main() -> int:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": (f"profiles/{traffic_tag}/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB "
                                             "per launch") if traffic else None,
-                         "kernel": "k_track_block", "kernel_ms": kernel_ms, "pyramid_ms": pyramid_ms,
+                         "kernel": "k_track_block_pyr" if fused_kernel else "k_track_block", "kernel_ms": kernel_ms,
+                         "pyramid_ms": pyramid_ms,
                          "algorithmic_bytes_per_feature": b_alg, "features_per_launch": n_active_local,
                          "note": "compulsory HBM bytes are ~3.2 KB/feature: the kernel is bound by the ordered f64 "
-                                 "accumulation chain (dependent-FMA latency), not by HBM; see DESIGN.md"},
+                                 "accumulation chain (dependent-FMA latency), not by HBM; see DESIGN.md"
+                                 + ("; the fused launch also builds the next frame's pyramid (6.56 B/pixel, not counted in "
+                                    "`achieved`, included in `traffic`)" if fused_kernel else "")},
         }
         # iterations executed (the rate is meaningless without it) and parity, rank 0 shard
         it = res["iters"][:n_total]
