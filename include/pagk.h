@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 100 /* 0.1.0 */
+#define PAGK_VERSION 200 /* 0.2.0 */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -36,7 +36,9 @@ enum {
     PAGK_E_HIP = -2,         /* a HIP runtime call failed (see pagk_last_error)           */
     PAGK_E_NOMEM = -3,       /* device or host allocation failed                          */
     PAGK_E_UNSUPPORTED = -4, /* inverse-compositional mode (reference: "not support yet") */
-    PAGK_E_NODEVICE = -5     /* no HIP device / HIP library could not initialise          */
+    PAGK_E_NODEVICE = -5,    /* no HIP device / HIP library could not initialise          */
+    PAGK_E_NCCL = -6,        /* an RCCL call of the sharded path failed (see pagk_last_error) */
+    PAGK_E_CAPACITY = -7     /* a caller-sized output array is too small (neighbour lists)  */
 };
 
 /* 8-bit single-channel image view.  Mirrors the fields of cv::Mat (CV_8UC1) the
@@ -248,6 +250,48 @@ int pagk_geometry_select(float score_H, float score_F);
 int pagk_geometry_validation(pagk_ctx *ctx, const double *H21, const double *H12, const double *F21,
                              int32_t n, const float *pt_ref_un, const float *pt_predict_un,
                              uint8_t *status, float sigma, float *track_score);
+
+/* ---- NCC nearest-neighbour matching ------------------------------ */
+/* GyroAidedTracker::FindAndSortNearNeighbor (src/gyro_aided_tracker.cpp:788-851) for all n reference keypoints
+ * (the reference's cv::parallel_for_ over [0, mN), :912): for every feature with status 1 and no neighbours yet,
+ * the current keypoints j whose undistorted position lies within level * radius_unit of the predicted point in
+ * both coordinates (:811-815), each scored with the free NCC (src/utils.cpp:110-148) of the reference patch
+ * around mvKeysRef[i].pt against the patch around mvKeysCur[j].pt warped by the feature's affine A -- sampled
+ * with the free GetPixelValue of include/utils.h:32-46 (`>` clamp, four-term formula), not with
+ * PatchMatch::GetPixelValue -- and sorted by the two-stack insertion of :825-842 (best first; equal keys: the
+ * later index first).
+ *   keys_ref      n x 2  mvKeysRef[i].pt           pt_predict_un  n x 2  mvPtPredictUn[i]
+ *   status        n      mvStatus[i]               affine         n x 4  mvAffineDeformationMatrix[i]; NULL = empty Mat
+ *   keys_cur      m x 2  mvKeysCur[j].pt           keys_cur_un    m x 2  mvKeysCurUn[j].pt
+ *   level                1 or 2 (:912, :922)       radius_unit           mRadiusForFindNearNeighbor (= 2 * h, :62)
+ *   use_ncc              mbNCC (:60: true); 0 sorts by distance, nearest first
+ *   count         n      IN/OUT: mvvNearNeighbors[i].size(); features with count > 0 are skipped (:793), so a
+ *                        second call with level 2 only fills the features the first left empty.  Zero it first.
+ *   nbr_idx/dist/ncc  n x cap  sMatch::trainIdx / distance / ncc of the sorted lists (queryIdx = i, level = level)
+ * pagk_near_neighbors_device: frames in slots (level 0 is used), device pointers, asynchronous on the context
+ * stream; a list longer than cap leaves only its true size in d_count[i].  pagk_find_near_neighbors: host
+ * buffers, synchronous; returns PAGK_E_CAPACITY when a list did not fit (count[] then holds the sizes needed). */
+int pagk_near_neighbors_device(pagk_ctx *ctx, int32_t slot_ref, int32_t slot_cur, int32_t half_patch, int32_t n,
+                               const float *d_keys_ref, const float *d_pt_predict_un, const uint8_t *d_status,
+                               const float *d_affine, int32_t m, const float *d_keys_cur, const float *d_keys_cur_un,
+                               int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *d_count,
+                               int32_t *d_nbr_idx, float *d_nbr_dist, float *d_nbr_ncc);
+int pagk_find_near_neighbors(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                             const float *keys_ref, const float *pt_predict_un, const uint8_t *status,
+                             const float *affine, int32_t m, const float *keys_cur, const float *keys_cur_un,
+                             int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *count,
+                             int32_t *nbr_idx, float *nbr_dist, float *nbr_ncc);
+/* The free NCC(halfPatchSize, ref, cur, pt_ref, pt_cur, warp_mat) of src/utils.cpp:166-200 for n point pairs
+ * (affine: n x 4 or NULL = empty warp_mat).  Host buffers, synchronous. */
+int pagk_ncc_free(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                  const float *pt_ref, const float *pt_cur, const float *affine, float *ncc);
+/* GyroAidedTracker::MatchFeatures (src/gyro_aided_tracker.cpp:949-1008) on the lists above: thresholds
+ * TH_NCC_HIGH 0.6, TH_NCC_LOW 0.3, TH_RATIO 0.75 (:7-9), one match per current keypoint -- a keypoint claimed
+ * twice loses every match and stays banned (:991-1005).  Host-side (sequential by nature).  match_*: capacity n
+ * (match_dist / match_ncc may be NULL).  Returns mvMatches.size() or a negative error. */
+int pagk_match_features(int32_t n, int32_t cap, const int32_t *count, const int32_t *nbr_idx, const float *nbr_dist,
+                        const float *nbr_ncc, int32_t use_ncc, int32_t *match_query, int32_t *match_train,
+                        float *match_dist, float *match_ncc);
 
 #ifdef __cplusplus
 }

@@ -945,3 +945,236 @@ int pagk_oracle_geometry_validation(const double *H21, const double *H12, const 
     free(idx), free(p1), free(p2), free(inH), free(inF);
     return rc == PAGK_OK ? cnt_inlier : rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * NCC nearest-neighbour matching,
+ * GyroAidedTracker::FindAndSortNearNeighbor / MatchFeatures (src/gyro_aided_tracker.cpp:788-851,
+ * 949-1008) over the FREE functions GetPixelValue (include/utils.h:32-46) and NCC
+ * (src/utils.cpp:110-148).  The free sampler is not the member PatchMatch::GetPixelValue: its upper
+ * clamp is `>` (x == cols stays), and its formula is the un-factored four-term sum.
+ * ---------------------------------------------------------------------------------------------- */
+static inline float get_pixel_value_free(const level_t *img, float x, float y)
+{
+    /* include/utils.h:35-38.  NaN is mapped to 0 like in the member sampler above (int(NaN) is undefined
+     * in the reference); identical for every non-NaN coordinate. */
+    if (!(x >= 0)) x = 0;
+    if (!(y >= 0)) y = 0;
+    if (x > img->cols) x = img->cols - 1;
+    if (y > img->rows) y = img->rows - 1;
+    int ix = (int)x, iy = (int)y;
+    int64_t off = (int64_t)iy * img->step + ix; /* :40 */
+    float xx = x - floorf(x);
+    float yy = y - floorf(y);
+    /* :43-44  (1 - yy) * (1 - xx) * data[0] + (1 - yy) * xx * data[1] + yy * (1 - xx) * data[step] + yy * xx * data[step+1]
+     * -- left to right: ((1-yy)*(1-xx))*d0, sums in order */
+    float pixel = (1 - yy) * (1 - xx) * tap(img, off) + (1 - yy) * xx * tap(img, off + 1) +
+                  yy * (1 - xx) * tap(img, off + img->step) + yy * xx * tap(img, off + img->step + 1);
+    return pixel;
+}
+
+/* NCC(halfPatchSize, vValuesRef, mean_ref, cur, pt_cur, warp_mat), src/utils.cpp:110-148. */
+static float ncc_free(int h, const float *v_ref, float mean_ref, const level_t *cur, float cx, float cy, const float *A,
+                      float *v_cur /* scratch, P floats */)
+{
+    const int P = (2 * h + 1) * (2 * h + 1);
+    float mean_cur = 0.0f;
+    int k = 0;
+    for (int x = -h; x <= h; x++) /* :120-121  x outer, y inner */
+        for (int y = -h; y <= h; y++) {
+            float value_cur;
+            if (!A) /* warp_mat.empty() :124 */
+                value_cur = get_pixel_value_free(cur, cx + x, cy + y);
+            else {
+                float wx = A[0] * x + A[1] * y; /* :127-128 */
+                float wy = A[2] * x + A[3] * y;
+                value_cur = get_pixel_value_free(cur, cx + wx, cy + wy);
+            }
+            mean_cur += value_cur;
+            v_cur[k++] = value_cur;
+        }
+    mean_cur /= (float)P; /* :135  float /= size_t */
+    float numerator = 0, den1 = 0, den2 = 0;
+    for (int i = 0; i < P; i++) { /* :139-145 */
+        float v_ref_dot = v_ref[i] - mean_ref;
+        float v_cur_dot = v_cur[i] - mean_cur;
+        numerator += (v_ref_dot * v_cur_dot);
+        den1 += v_ref_dot * v_ref_dot;
+        den2 += v_cur_dot * v_cur_dot;
+    }
+    return (float)((double)numerator / sqrt((double)(den1 * den2) + 1e-10)); /* :147 */
+}
+
+/* NCC(halfPatchSize, ref, cur, pt_ref, pt_cur, warp_mat), src/utils.cpp:166-200 (the two-image overload). */
+float pagk_oracle_ncc_free(const pagk_image *ref, const pagk_image *cur, int32_t half_patch, float rx, float ry,
+                           float cx, float cy, const float *A)
+{
+    level_t lr, lc;
+    if (view_to_level(ref, &lr) || view_to_level(cur, &lc) || half_patch < 1) return NAN;
+    const int h = half_patch, P = (2 * h + 1) * (2 * h + 1);
+    float *vr = (float *)malloc(sizeof(float) * 2 * (size_t)P), *vc = vr + P;
+    if (!vr) return NAN;
+    float mean_ref = 0.0f, mean_cur = 0.0f;
+    int k = 0;
+    for (int x = -h; x <= h; x++)
+        for (int y = -h; y <= h; y++) {
+            float value_ref = get_pixel_value_free(&lr, rx + x, ry + y);
+            mean_ref += value_ref;
+            vr[k] = value_ref;
+            float value_cur;
+            if (!A)
+                value_cur = get_pixel_value_free(&lc, cx + x, cy + y);
+            else {
+                float wx = A[0] * x + A[1] * y;
+                float wy = A[2] * x + A[3] * y;
+                value_cur = get_pixel_value_free(&lc, cx + wx, cy + wy);
+            }
+            mean_cur += value_cur;
+            vc[k] = value_cur;
+            k++;
+        }
+    mean_ref /= (float)P;
+    mean_cur /= (float)P;
+    float numerator = 0, den1 = 0, den2 = 0;
+    for (int i = 0; i < P; i++) { /* :193-197: differences re-evaluated per term */
+        numerator += ((vr[i] - mean_ref) * (vc[i] - mean_cur));
+        den1 += (vr[i] - mean_ref) * (vr[i] - mean_ref);
+        den2 += (vc[i] - mean_cur) * (vc[i] - mean_cur);
+    }
+    free(vr);
+    return (float)((double)numerator / sqrt((double)(den1 * den2) + 1e-10));
+}
+
+typedef struct {
+    int train;
+    float distance, ncc;
+} nn_t;
+
+/* GyroAidedTracker::FindAndSortNearNeighbor, src/gyro_aided_tracker.cpp:788-851, for range [0, n). */
+int pagk_oracle_find_near_neighbors(const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                                    const float *keys_ref, const float *pt_predict_un, const uint8_t *status,
+                                    const float *affine, int32_t m, const float *keys_cur, const float *keys_cur_un,
+                                    int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *count,
+                                    int32_t *nbr_idx, float *nbr_dist, float *nbr_ncc)
+{
+    level_t lr, lc;
+    if (view_to_level(ref, &lr) || view_to_level(cur, &lc)) return PAGK_E_ARG;
+    if (half_patch < 1 || n < 0 || m < 0 || cap < 1 || !count) return PAGK_E_ARG;
+    const int h = half_patch, P = (2 * h + 1) * (2 * h + 1);
+    float *v_ref = (float *)malloc(sizeof(float) * 2 * (size_t)P), *v_cur = v_ref + P;
+    nn_t *st1 = (nn_t *)malloc(sizeof(nn_t) * 2 * (size_t)(m > 0 ? m : 1)), *st2 = st1 + (m > 0 ? m : 1);
+    if (!v_ref || !st1) {
+        free(v_ref);
+        free(st1);
+        return PAGK_E_NOMEM;
+    }
+    int overflow = 0;
+    for (int i = 0; i < n; i++) {
+        if (!status[i]) continue;     /* :791 */
+        if (count[i] > 0) continue;   /* :793  neighbours already found with a smaller search region */
+        /* :800-808  reference patch values and mean, x outer / y inner, on mvKeysRef[i].pt */
+        float mean_ref = 0.0f;
+        int k = 0;
+        for (int x = -h; x <= h; x++)
+            for (int y = -h; y <= h; y++) {
+                float value_ref = get_pixel_value_free(&lr, keys_ref[2 * i] + x, keys_ref[2 * i + 1] + y);
+                mean_ref += value_ref;
+                v_ref[k++] = value_ref;
+            }
+        mean_ref /= (float)P;
+        const float radius = (float)level * radius_unit; /* :811 */
+        int n1 = 0, n2 = 0; /* the two std::stack of :797 as arrays; top = last element */
+        for (int j = 0; j < m; j++) {
+            float dx = pt_predict_un[2 * i] - keys_cur_un[2 * j], dy = pt_predict_un[2 * i + 1] - keys_cur_un[2 * j + 1];
+            if (fabsf(dx) > radius || fabsf(dy) > radius) continue; /* :814 */
+            float distance = sqrtf(dx * dx + dy * dy);              /* :818 */
+            float ncc = ncc_free(h, v_ref, mean_ref, &lc, keys_cur[2 * j], keys_cur[2 * j + 1],
+                                 affine ? affine + 4 * i : NULL, v_cur); /* :821 */
+            nn_t match = {j, distance, ncc};
+            if (use_ncc) { /* :825-830 */
+                while (n1 > 0 && ncc < st1[n1 - 1].ncc) st2[n2++] = st1[--n1];
+            } else {       /* :831-836 */
+                while (n1 > 0 && distance > st1[n1 - 1].distance) st2[n2++] = st1[--n1];
+            }
+            st1[n1++] = match;                      /* :838 */
+            while (n2 > 0) st1[n1++] = st2[--n2];   /* :839-842 */
+        }
+        count[i] = n1;
+        if (n1 > cap) {
+            overflow = 1;
+            continue;
+        }
+        for (int k2 = 0; k2 < n1; k2++) { /* :845-849  popped from the top */
+            const nn_t *e = &st1[n1 - 1 - k2];
+            nbr_idx[(size_t)i * cap + k2] = e->train;
+            nbr_dist[(size_t)i * cap + k2] = e->distance;
+            nbr_ncc[(size_t)i * cap + k2] = e->ncc;
+        }
+    }
+    free(v_ref);
+    free(st1);
+    return overflow ? PAGK_E_ARG : PAGK_OK;
+}
+
+/* GyroAidedTracker::MatchFeatures, src/gyro_aided_tracker.cpp:949-1008.  TH_NCC_HIGH = 0.6f,
+ * TH_NCC_LOW = 0.3f, TH_RATIO = 0.75f (:7-9).  Returns the number of matches. */
+int pagk_oracle_match_features(int32_t n, int32_t cap, const int32_t *count, const int32_t *nbr_idx,
+                               const float *nbr_dist, const float *nbr_ncc, int32_t use_ncc, int32_t *match_query,
+                               int32_t *match_train, float *match_dist, float *match_ncc)
+{
+    const float TH_NCC_HIGH = 0.6f, TH_NCC_LOW = 0.3f, TH_RATIO = 0.75f;
+    int nm = 0;
+    for (int i = 0; i < n; i++) {
+        const int c = count[i];
+        if (c <= 0) continue; /* :955 */
+        const size_t b = (size_t)i * cap;
+        if (use_ncc) {
+            if (nbr_ncc[b] > TH_NCC_HIGH) { /* :961 */
+            } else if (c > 1) {
+                if (nbr_ncc[b] < TH_NCC_LOW) continue;               /* :964 */
+                if (!(nbr_ncc[b + 1] < nbr_ncc[b] * TH_RATIO)) continue; /* :968-971 */
+            } else
+                continue;
+        } else {
+            if (c == 1) { /* :978 */
+            } else if (!(nbr_dist[b] < nbr_dist[b + 1] * TH_RATIO))
+                continue; /* :982-985 */
+        }
+        const int train = nbr_idx[b];
+        match_query[nm] = i;
+        match_train[nm] = train;
+        match_dist[nm] = nbr_dist[b];
+        match_ncc[nm] = nbr_ncc[b];
+        nm++;
+    }
+    /* second pass: the std::set / erase logic of :991-1005 replayed in order over the candidates chosen above */
+    int out = 0;
+    int32_t *seen = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nm > 0 ? nm : 1));
+    int nseen = 0;
+    if (!seen) return PAGK_E_NOMEM;
+    for (int k = 0; k < nm; k++) {
+        const int train = match_train[k];
+        int in_set = 0;
+        for (int s = 0; s < nseen && !in_set; s++) in_set = seen[s] == train;
+        if (!in_set) { /* :991-994 */
+            match_query[out] = match_query[k];
+            match_train[out] = train;
+            match_dist[out] = match_dist[k];
+            match_ncc[out] = match_ncc[k];
+            out++;
+            seen[nseen++] = train;
+        } else { /* :995-1005  erase every earlier match to this keypoint; the index stays in the set */
+            int w = 0;
+            for (int r = 0; r < out; r++)
+                if (match_train[r] != train) {
+                    match_query[w] = match_query[r];
+                    match_train[w] = match_train[r];
+                    match_dist[w] = match_dist[r];
+                    match_ncc[w] = match_ncc[r];
+                    w++;
+                }
+            out = w;
+        }
+    }
+    free(seen);
+    return out;
+}

@@ -90,6 +90,31 @@ int pagk_oracle_geometry_validation(const double *H21, const double *H12, const 
                                     const float *pt_ref_un, const float *pt_predict_un, uint8_t *status,
                                     float sigma, float *track_score);
 
+/* ---- NCC nearest-neighbour matching ------------------------------------------- */
+/* Free NCC(halfPatchSize, ref, cur, pt_ref, pt_cur, warp_mat), src/utils.cpp:166-200, over the free
+ * GetPixelValue of include/utils.h:32-46 (NOT PatchMatch::GetPixelValue).  A: 2x2 row-major or NULL (empty Mat). */
+float pagk_oracle_ncc_free(const pagk_image *ref, const pagk_image *cur, int32_t half_patch, float rx, float ry,
+                           float cx, float cy, const float *A);
+/* GyroAidedTracker::FindAndSortNearNeighbor (src/gyro_aided_tracker.cpp:788-851) over [0, n).
+ *   keys_ref      n x 2  mvKeysRef[i].pt          pt_predict_un n x 2  mvPtPredictUn[i]
+ *   status        n      mvStatus[i]              affine        n x 4  mvAffineDeformationMatrix[i] or NULL (empty)
+ *   keys_cur      m x 2  mvKeysCur[j].pt          keys_cur_un   m x 2  mvKeysCurUn[j].pt
+ *   level, radius_unit   search radius = level * mRadiusForFindNearNeighbor (:811; the tracker sets 2 * h, :62)
+ *   use_ncc              mbNCC (:60 true)
+ *   count         n      in/out: size of mvvNearNeighbors[i]; features with count > 0 are skipped (:793)
+ *   nbr_*         n x cap  the sorted neighbour lists (trainIdx, distance, ncc), best first
+ * Returns PAGK_OK, or PAGK_E_ARG when a list is longer than cap (count[] then still holds the true sizes). */
+int pagk_oracle_find_near_neighbors(const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                                    const float *keys_ref, const float *pt_predict_un, const uint8_t *status,
+                                    const float *affine, int32_t m, const float *keys_cur, const float *keys_cur_un,
+                                    int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *count,
+                                    int32_t *nbr_idx, float *nbr_dist, float *nbr_ncc);
+/* GyroAidedTracker::MatchFeatures (src/gyro_aided_tracker.cpp:949-1008).  match_*: capacity n.  Returns the
+ * number of matches (mvMatches.size()). */
+int pagk_oracle_match_features(int32_t n, int32_t cap, const int32_t *count, const int32_t *nbr_idx,
+                               const float *nbr_dist, const float *nbr_ncc, int32_t use_ncc, int32_t *match_query,
+                               int32_t *match_train, float *match_dist, float *match_ncc);
+
 #ifdef __cplusplus
 }
 #endif

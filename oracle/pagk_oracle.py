@@ -59,6 +59,13 @@ def load():
         lib.pagk_oracle_geometry_select.argtypes = [f32, f32]
         lib.pagk_oracle_geometry_validation.restype = C.c_int
         lib.pagk_oracle_geometry_validation.argtypes = [vp, vp, vp, i32, vp, vp, vp, f32, P(f32)]
+        lib.pagk_oracle_ncc_free.restype = f32
+        lib.pagk_oracle_ncc_free.argtypes = [P(Image), P(Image), i32, f32, f32, f32, f32, vp]
+        lib.pagk_oracle_find_near_neighbors.restype = C.c_int
+        lib.pagk_oracle_find_near_neighbors.argtypes = [P(Image), P(Image), i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32,
+                                                        i32, i32, vp, vp, vp, vp]
+        lib.pagk_oracle_match_features.restype = C.c_int
+        lib.pagk_oracle_match_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
         _lib = lib
     return _lib
 
@@ -189,3 +196,44 @@ def geometry_validation(H21, H12, F21, pt_ref_un, pt_predict_un, status, sigma=1
     if rc < 0:
         raise RuntimeError(f"pagk_oracle_geometry_validation: {rc}")
     return rc, st, np.float32(ts.value)
+
+
+def ncc_free(img_ref, img_cur, half_patch, pt_ref, pt_cur, A=None) -> np.float32:
+    """Free NCC over the free GetPixelValue (reference src/utils.cpp:166-200, include/utils.h:32-46)."""
+    ir, ic = image_view(img_ref), image_view(img_cur)
+    A = None if A is None else np.ascontiguousarray(A, np.float32).reshape(4)
+    return np.float32(load().pagk_oracle_ncc_free(C.byref(ir), C.byref(ic), half_patch, float(pt_ref[0]), float(pt_ref[1]),
+                                                  float(pt_cur[0]), float(pt_cur[1]), _p(A)))
+
+
+def find_near_neighbors(img_ref, img_cur, half_patch, keys_ref, pt_predict_un, status, affine, keys_cur, keys_cur_un,
+                        level=1, radius_unit=None, use_ncc=True, cap=64, count=None):
+    """FindAndSortNearNeighbor (reference src/gyro_aided_tracker.cpp:788-851) -> dict(count, idx, dist, ncc, rc)."""
+    n, m = int(keys_ref.shape[0]), int(keys_cur.shape[0])
+    ir, ic = image_view(img_ref), image_view(img_cur)
+    count = np.zeros(max(n, 1), np.int32) if count is None else np.array(count, np.int32, copy=True)
+    idx = np.full((max(n, 1), cap), -1, np.int32)
+    dist = np.zeros((max(n, 1), cap), np.float32)
+    ncc = np.zeros((max(n, 1), cap), np.float32)
+    ru = float(2 * half_patch) if radius_unit is None else float(radius_unit)
+    rc = load().pagk_oracle_find_near_neighbors(C.byref(ir), C.byref(ic), half_patch, n, _p(keys_ref), _p(pt_predict_un),
+                                                _p(status), _p(affine), m, _p(keys_cur), _p(keys_cur_un), level, ru,
+                                                int(use_ncc), cap, _p(count), _p(idx), _p(dist), _p(ncc))
+    return dict(count=count[:n], idx=idx[:n], dist=dist[:n], ncc=ncc[:n], rc=rc)
+
+
+def match_features(count, idx, dist, ncc, use_ncc=True):
+    """MatchFeatures (reference src/gyro_aided_tracker.cpp:949-1008) -> (query, train, dist, ncc) arrays."""
+    n = int(count.shape[0])
+    cap = int(idx.shape[1]) if idx.ndim == 2 else 1
+    q = np.zeros(max(n, 1), np.int32)
+    t = np.zeros(max(n, 1), np.int32)
+    d = np.zeros(max(n, 1), np.float32)
+    c = np.zeros(max(n, 1), np.float32)
+    idx, dist, ncc = (np.ascontiguousarray(a) for a in (idx, dist, ncc))
+    count = np.ascontiguousarray(count, np.int32)
+    k = load().pagk_oracle_match_features(n, cap, _p(count), _p(idx), _p(dist), _p(ncc), int(use_ncc), _p(q), _p(t),
+                                          _p(d), _p(c))
+    if k < 0:
+        raise RuntimeError(f"pagk_oracle_match_features: {k}")
+    return q[:k], t[:k], d[:k], c[:k]

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libpagk_hip.so")
+# PAGK_LIB: an alternative build of the same library (same-session A/B runs of tools/ab_lib.py; never a CPU path)
+LIB_PATH = os.environ.get("PAGK_LIB") or os.path.join(PKG_DIR, "libpagk_hip.so")
 
 PAGK_OK = 0
 PAGK_E_ARG = -1
@@ -19,6 +20,8 @@ PAGK_E_HIP = -2
 PAGK_E_NOMEM = -3
 PAGK_E_UNSUPPORTED = -4
 PAGK_E_NODEVICE = -5
+PAGK_E_NCCL = -6
+PAGK_E_CAPACITY = -7
 
 
 class Image(C.Structure):
@@ -180,6 +183,16 @@ def declare(lib) -> None:
     lib.pagk_geometry_select.argtypes = [f32, f32]
     lib.pagk_geometry_validation.restype = C.c_int
     lib.pagk_geometry_validation.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, f32, _P(f32)]
+    lib.pagk_near_neighbors_device.restype = C.c_int
+    lib.pagk_near_neighbors_device.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, i32, i32,
+                                               vp, vp, vp, vp]
+    lib.pagk_find_near_neighbors.restype = C.c_int
+    lib.pagk_find_near_neighbors.argtypes = [vp, _P(Image), _P(Image), i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32,
+                                             i32, i32, vp, vp, vp, vp]
+    lib.pagk_ncc_free.restype = C.c_int
+    lib.pagk_ncc_free.argtypes = [vp, _P(Image), _P(Image), i32, i32, vp, vp, vp, vp]
+    lib.pagk_match_features.restype = C.c_int
+    lib.pagk_match_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
 
 
 EXPORTED_SYMBOLS = [
@@ -190,6 +203,7 @@ EXPORTED_SYMBOLS = [
     "pagk_gyro_predict_device_rot",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
     "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
+    "pagk_near_neighbors_device", "pagk_find_near_neighbors", "pagk_ncc_free", "pagk_match_features",
 ]
 
 
@@ -351,6 +365,44 @@ class Context:
             self._check(rc, "pagk_geometry_validation")
         return rc, st, np.float32(ts.value)
 
+    # NCC nearest-neighbour matching ------------------------------
+    def find_near_neighbors(self, img_ref, img_cur, half_patch, keys_ref, pt_predict_un, status, affine, keys_cur,
+                            keys_cur_un, level=1, radius_unit=None, use_ncc=True, cap=64, count=None):
+        """FindAndSortNearNeighbor (reference src/gyro_aided_tracker.cpp:788-851), host buffers ->
+        dict(count, idx, dist, ncc, rc); rc is PAGK_OK or PAGK_E_CAPACITY (count then holds the sizes needed)."""
+        n, m = int(keys_ref.shape[0]), int(keys_cur.shape[0])
+        ir, ic = image_view(img_ref), image_view(img_cur)
+        count = np.zeros(max(n, 1), np.int32) if count is None else np.array(count, np.int32, copy=True)
+        idx = np.full((max(n, 1), cap), -1, np.int32)
+        dist = np.zeros((max(n, 1), cap), np.float32)
+        ncc = np.zeros((max(n, 1), cap), np.float32)
+        ru = float(2 * half_patch) if radius_unit is None else float(radius_unit)
+        rc = self.lib.pagk_find_near_neighbors(self.h, C.byref(ir), C.byref(ic), half_patch, n, _ptr(keys_ref),
+                                               _ptr(pt_predict_un), _ptr(status), _ptr(affine), m, _ptr(keys_cur),
+                                               _ptr(keys_cur_un), level, ru, int(use_ncc), cap, _ptr(count), _ptr(idx),
+                                               _ptr(dist), _ptr(ncc))
+        if rc not in (PAGK_OK, PAGK_E_CAPACITY):
+            self._check(rc, "pagk_find_near_neighbors")
+        return dict(count=count[:n], idx=idx[:n], dist=dist[:n], ncc=ncc[:n], rc=rc)
+
+    def near_neighbors_device(self, slot_ref, slot_cur, half_patch, n, d_keys_ref, d_pt_predict_un, d_status, d_affine,
+                              m, d_keys_cur, d_keys_cur_un, level, radius_unit, use_ncc, cap, d_count, d_idx, d_dist,
+                              d_ncc):
+        self._check(self.lib.pagk_near_neighbors_device(self.h, slot_ref, slot_cur, half_patch, n, _ptr(d_keys_ref),
+                                                        _ptr(d_pt_predict_un), _ptr(d_status), _ptr(d_affine), m,
+                                                        _ptr(d_keys_cur), _ptr(d_keys_cur_un), level, float(radius_unit),
+                                                        int(use_ncc), cap, _ptr(d_count), _ptr(d_idx), _ptr(d_dist),
+                                                        _ptr(d_ncc)), "pagk_near_neighbors_device")
+
+    def ncc_free(self, img_ref, img_cur, half_patch, pt_ref, pt_cur, affine=None) -> np.ndarray:
+        """The free NCC of reference src/utils.cpp:166-200 for n point pairs (host buffers)."""
+        n = int(pt_ref.shape[0])
+        ir, ic = image_view(img_ref), image_view(img_cur)
+        out = np.zeros(max(n, 1), np.float32)
+        self._check(self.lib.pagk_ncc_free(self.h, C.byref(ir), C.byref(ic), half_patch, n, _ptr(pt_ref), _ptr(pt_cur),
+                                           _ptr(affine), _ptr(out)), "pagk_ncc_free")
+        return out[:n]
+
     def gyro_predict_device_rot(self, params: Params, width: int, height: int, d_rot, n: int, d_pt_ref,
                                 d_pt_predict_un, d_pt_predict, d_status, d_affine):
         """Prediction with the rotation (KRKinv rows 0-1, r3: 9 floats) in device memory: capturable per frame."""
@@ -406,3 +458,19 @@ def post_filter(half_patch: int, status_pm, pix_err, dist_pred, pt_pm, pt_pm_un)
 def geometry_select(score_H: float, score_F: float) -> bool:
     """True = homography chosen (RH > 0.45, reference src/gyro_aided_tracker.cpp:462-470)."""
     return bool(load().pagk_geometry_select(float(score_H), float(score_F)))
+
+
+def match_features(count, idx, dist, ncc, use_ncc=True):
+    """pagk_match_features: GyroAidedTracker::MatchFeatures (reference src/gyro_aided_tracker.cpp:949-1008)
+    -> (query, train, dist, ncc) of the accepted matches."""
+    n = int(count.shape[0])
+    cap = int(idx.shape[1])
+    q, t = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    d, c = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    count = np.ascontiguousarray(count, np.int32)
+    idx, dist, ncc = np.ascontiguousarray(idx), np.ascontiguousarray(dist), np.ascontiguousarray(ncc)
+    k = load().pagk_match_features(n, cap, _ptr(count), _ptr(idx), _ptr(dist), _ptr(ncc), int(use_ncc), _ptr(q), _ptr(t),
+                                   _ptr(d), _ptr(c))
+    if k < 0:
+        raise PagkError(k, "pagk_match_features")
+    return q[:k], t[:k], d[:k], c[:k]

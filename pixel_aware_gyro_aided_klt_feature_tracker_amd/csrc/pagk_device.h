@@ -95,12 +95,47 @@ __device__ __forceinline__ float bilerp(uint32_t q, const Coord &cx, const Coord
     return cy.omf * top + cy.f * bot;
 }
 
+#ifdef PAGK_TYPED_TAPS
+// The four taps of a quad arrive as four floats: the texture addresser converts them.  A quad dword is read
+// through a buffer resource whose element format is 8_8_8_8 / USCALED (unsigned byte -> float, exact), so
+// `buffer_load_format_xyzw` returns (float)byte0..3 and the 4 x v_cvt_f32_ubyte per sample disappear from the
+// VALU stream; `idxen` with a 4-byte stride takes the element index as is (no 64-bit address arithmetic).
+// clang has no builtin for the format loads; the LLVM intrinsic is reached through its asm label.
+typedef float pagk_f32x4 __attribute__((ext_vector_type(4)));
+typedef int pagk_i32x4 __attribute__((ext_vector_type(4)));
+__device__ pagk_f32x4 pagk_buffer_load_format_xyzw(pagk_i32x4 rsrc, int vindex, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.struct.buffer.load.format.v4f32");
+
+__device__ __forceinline__ pagk_i32x4 tap_rsrc(const DevLevel &L)
+{
+    const uint64_t base = (uint64_t)(uintptr_t)L.quad;
+    pagk_i32x4 r;
+    r.x = (int)(uint32_t)base;
+    r.y = (int)((uint32_t)(base >> 32) & 0xffffu) | (4 << 16);  // stride 4 bytes
+    r.z = L.cols * L.rows;                                       // records
+    // dst_sel x,y,z,w = R,G,B,A; num_format USCALED (2); data_format 8_8_8_8 (10)
+    r.w = 4 | (5 << 3) | (6 << 6) | (7 << 9) | (2 << 12) | (10 << 15);
+    return r;
+}
+
+__device__ __forceinline__ float bilerp4(pagk_f32x4 d, const Coord &cx, const Coord &cy)
+{
+    float top = cx.omf * d.x + cx.f * d.y;
+    float bot = cx.omf * d.z + cx.f * d.w;
+    return cy.omf * top + cy.f * bot;
+}
+#endif
+
 template <bool CLAMP>
 __device__ __forceinline__ float sample(const DevLevel &L, float x, float y)
 {
     Coord cx = prep_coord<CLAMP>(x, L.fcols, L.fcols_m1);
     Coord cy = prep_coord<CLAMP>(y, L.frows, L.frows_m1);
+#ifdef PAGK_TYPED_TAPS
+    return bilerp4(pagk_buffer_load_format_xyzw(tap_rsrc(L), __mul24(cy.i, L.cols) + cx.i, 0, 0, 0), cx, cy);
+#else
     return bilerp(L.quad[(uint32_t)(__mul24(cy.i, L.cols) + cx.i)], cx, cy);
+#endif
 }
 
 // The five img2 samples one pixel of the GN loop needs (src/patch_match.cpp:252,259-262):
@@ -118,21 +153,35 @@ __device__ __forceinline__ Five sample5(const DevLevel &L, float X, float Y)
     Coord cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
     Coord cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
     Coord cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
-    const uint32_t *q = L.quad;
     // row offsets: both factors are < 2^24 (checked at upload), full-rate 24-bit multiply
     int rc = __mul24(cy.i, L.cols), rp = __mul24(cyp.i, L.cols), rm = __mul24(cym.i, L.cols);
+    Five r;
+#ifdef PAGK_TYPED_TAPS
+    const pagk_i32x4 rs = tap_rsrc(L);
+    pagk_f32x4 q0 = pagk_buffer_load_format_xyzw(rs, rc + cx.i, 0, 0, 0);
+    pagk_f32x4 q1 = pagk_buffer_load_format_xyzw(rs, rc + cxp.i, 0, 0, 0);
+    pagk_f32x4 q2 = pagk_buffer_load_format_xyzw(rs, rc + cxm.i, 0, 0, 0);
+    pagk_f32x4 q3 = pagk_buffer_load_format_xyzw(rs, rp + cx.i, 0, 0, 0);
+    pagk_f32x4 q4 = pagk_buffer_load_format_xyzw(rs, rm + cx.i, 0, 0, 0);
+    r.c = bilerp4(q0, cx, cy);
+    r.xp = bilerp4(q1, cxp, cy);
+    r.xm = bilerp4(q2, cxm, cy);
+    r.yp = bilerp4(q3, cx, cyp);
+    r.ym = bilerp4(q4, cx, cym);
+#else
+    const uint32_t *q = L.quad;
     // unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
     uint32_t q0 = q[(uint32_t)(rc + cx.i)];
     uint32_t q1 = q[(uint32_t)(rc + cxp.i)];
     uint32_t q2 = q[(uint32_t)(rc + cxm.i)];
     uint32_t q3 = q[(uint32_t)(rp + cx.i)];
     uint32_t q4 = q[(uint32_t)(rm + cx.i)];
-    Five r;
     r.c = bilerp(q0, cx, cy);
     r.xp = bilerp(q1, cxp, cy);
     r.xm = bilerp(q2, cxm, cy);
     r.yp = bilerp(q3, cx, cyp);
     r.ym = bilerp(q4, cx, cym);
+#endif
     return r;
 }
 

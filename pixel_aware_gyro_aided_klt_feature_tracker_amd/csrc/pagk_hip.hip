@@ -23,6 +23,7 @@ constexpr int kUserSlots = 4;
 struct FrameSlot {
     int w = 0, h = 0, L = 0;
     int wrap0 = 1;                   // level-0 source was continuous (step == cols)
+    int pad0 = 0;                    // min(step - cols, 2) of the level-0 source (free GetPixelValue, x == cols)
     uint8_t *u8[kMaxLevels] = {};    // u8[0] is our contiguous copy of level 0 (pitch = w)
     uint32_t *quad[kMaxLevels] = {};
     void *block = nullptr;           // one allocation for everything above
@@ -177,6 +178,7 @@ bool pyramid_fusable(const FrameSlot &s)
 // already on the device at (src0, pitch0).
 int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0, int wrap0)
 {
+    s.pad0 = wrap0 ? 0 : 2;  // callers that know the source's step refine this (frame_upload_any, pagk_frame_set_device)
     int lw[kMaxLevels], lh[kMaxLevels];
     level_dims(s.w, s.h, s.L, lw, lh);
     dim3 blk(32, 8);
@@ -526,6 +528,8 @@ const char *pagk_strerror(int code)
         case PAGK_E_NOMEM: return "out of memory";
         case PAGK_E_UNSUPPORTED: return "unsupported mode";
         case PAGK_E_NODEVICE: return "no HIP device";
+        case PAGK_E_NCCL: return "RCCL error";
+        case PAGK_E_CAPACITY: return "output capacity too small";
         default: return "unknown error";
     }
 }
@@ -676,7 +680,9 @@ static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, 
     s.valid = false;
     if ((rc = slot_reserve(ctx, s, img->width, img->height, pyramids))) return rc;
     if ((rc = upload_level0(ctx, s, img))) return rc;
-    return slot_build(ctx, s, s.u8[0], s.w, img->step == img->width);
+    rc = slot_build(ctx, s, s.u8[0], s.w, img->step == img->width);
+    s.pad0 = (int)(img->step - img->width > 2 ? 2 : img->step - img->width);
+    return rc;
 }
 
 int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width, int32_t height,
@@ -691,7 +697,9 @@ int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32
     int rc = slot_reserve(ctx, s, width, height, pyramids);
     if (rc) return rc;
     // level 0 is read in place: no copy
-    return slot_build(ctx, s, static_cast<const uint8_t *>(d_data), step, step == width);
+    rc = slot_build(ctx, s, static_cast<const uint8_t *>(d_data), step, step == width);
+    s.pad0 = (int)(step - width > 2 ? 2 : step - width);
+    return rc;
 }
 
 int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst, int32_t *width,
@@ -765,6 +773,7 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
         if (rc) return rc;
         if (fused) {
             sn.wrap0 = wrap0;
+            sn.pad0 = (int)(step - width > 2 ? 2 : step - width);
             sn.valid = true;
             return PAGK_OK;
         }
@@ -772,7 +781,9 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
         rc = launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out);
         if (rc) return rc;
     }
-    return slot_build(ctx, sn, src0, step, wrap0);  // the launch selected another variant: pyramid on its own
+    rc = slot_build(ctx, sn, src0, step, wrap0);  // the launch selected another variant: pyramid on its own
+    sn.pad0 = (int)(step - width > 2 ? 2 : step - width);
+    return rc;
 }
 
 int pagk_track(pagk_ctx *ctx, const pagk_params *params, const pagk_image *ref, const pagk_image *cur, int32_t n,
@@ -849,6 +860,8 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels, c
                                im.width, im.height, im.step == im.width ? 1 : 0, s.quad[l]);
         }
         HIPCHK(ctx, hipGetLastError());
+        s.wrap0 = lv[k][0].step == lv[k][0].width;
+        s.pad0 = (int)(lv[k][0].step - lv[k][0].width > 2 ? 2 : lv[k][0].step - lv[k][0].width);
         s.valid = true;
     }
     return track_host_common(ctx, params, n, pt_ref_un, pt_init_un, affine, status_in, out, ctx->slots[4],
@@ -1109,6 +1122,226 @@ int pagk_geometry_validation(pagk_ctx *ctx, const double *H21, const double *H12
     }
     return cnt_inlier;
     } catch (const std::bad_alloc &) {  // nothing crosses the C ABI
+        return PAGK_E_NOMEM;
+    }
+}
+
+// ---- NCC nearest-neighbour matching ---------------------------------
+static int near_neighbors_launch(pagk_ctx *ctx, const FrameSlot &sr, const FrameSlot &sc, int32_t half_patch, int32_t n,
+                                 const float *d_keys_ref, const float *d_pt_predict_un, const uint8_t *d_status,
+                                 const float *d_affine, int32_t m, const float *d_keys_cur, const float *d_keys_cur_un,
+                                 int32_t level, float radius_unit, int32_t use_ncc, int32_t pairs, int32_t cap,
+                                 int32_t *d_count, int32_t *d_nbr_idx, float *d_nbr_dist, float *d_nbr_ncc)
+{
+    NeighborArgs a;
+    memset(&a, 0, sizeof a);
+    fill_level(a.ref0, sr, 0);
+    fill_level(a.cur0, sc, 0);
+    a.pad_ref = sr.pad0;
+    a.pad_cur = sc.pad0;
+    a.half = half_patch, a.n = n, a.m = m, a.cap = cap, a.level = level, a.use_ncc = use_ncc, a.pairs = pairs;
+    a.radius = (float)level * radius_unit;  // src/gyro_aided_tracker.cpp:811  int * float
+    a.keys_ref = d_keys_ref, a.pt_pred = d_pt_predict_un, a.affine = d_affine, a.status = d_status;
+    a.keys_cur = d_keys_cur, a.keys_cur_un = d_keys_cur_un;
+    a.count = d_count, a.nbr_idx = d_nbr_idx, a.nbr_dist = d_nbr_dist, a.nbr_ncc = d_nbr_ncc;
+    if (n <= 0) return PAGK_OK;
+    const int P = (2 * half_patch + 1) * (2 * half_patch + 1);
+    const int nr = (P + 255) / 256, tail = P % 32;
+    const size_t lds = neighbor_lds_bytes(half_patch, cap);
+    if (lds > 64 * 1024) {
+        snprintf(ctx->err, sizeof(ctx->err), "neighbour capacity %d needs %zu bytes of LDS (limit 64 KiB)", cap, lds);
+        return PAGK_E_ARG;
+    }
+    auto launch = [&](auto kern) -> hipError_t {
+        hipLaunchKernelGGL(kern, dim3(n), dim3(256), lds, ctx->stream, a);
+        return hipGetLastError();
+    };
+    hipError_t e = hipErrorInvalidValue;
+    switch (nr * 100 + tail) {  // (NR, TAIL) as for k_track_block
+        case 101: e = launch(k_near_neighbors<1, 1>); break;
+        case 109: e = launch(k_near_neighbors<1, 9>); break;
+        case 117: e = launch(k_near_neighbors<1, 17>); break;
+        case 125: e = launch(k_near_neighbors<1, 25>); break;
+        case 201: e = launch(k_near_neighbors<2, 1>); break;
+        case 209: e = launch(k_near_neighbors<2, 9>); break;
+        case 225: e = launch(k_near_neighbors<2, 25>); break;
+        case 317: e = launch(k_near_neighbors<3, 17>); break;
+        case 325: e = launch(k_near_neighbors<3, 25>); break;
+        case 409: e = launch(k_near_neighbors<4, 9>); break;
+        case 401: e = launch(k_near_neighbors<4, 1>); break;
+        default: break;
+    }
+    HIPCHK(ctx, e);
+    return PAGK_OK;
+}
+
+int pagk_near_neighbors_device(pagk_ctx *ctx, int32_t slot_ref, int32_t slot_cur, int32_t half_patch, int32_t n,
+                               const float *d_keys_ref, const float *d_pt_predict_un, const uint8_t *d_status,
+                               const float *d_affine, int32_t m, const float *d_keys_cur, const float *d_keys_cur_un,
+                               int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *d_count,
+                               int32_t *d_nbr_idx, float *d_nbr_dist, float *d_nbr_ncc)
+{
+    if (!ctx || slot_ref < 0 || slot_ref >= kUserSlots || slot_cur < 0 || slot_cur >= kUserSlots) return PAGK_E_ARG;
+    if (half_patch < 1 || half_patch > PAGK_MAX_HALF_PATCH || n < 0 || m < 0 || cap < 1 || level < 0) return PAGK_E_ARG;
+    if (n > 0 && (!d_keys_ref || !d_pt_predict_un || !d_status || !d_count || !d_nbr_idx || !d_nbr_dist || !d_nbr_ncc))
+        return PAGK_E_ARG;
+    if (n > 0 && m > 0 && (!d_keys_cur || !d_keys_cur_un)) return PAGK_E_ARG;
+    const FrameSlot &sr = ctx->slots[slot_ref], &sc = ctx->slots[slot_cur];
+    if (!sr.valid || !sc.valid) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return near_neighbors_launch(ctx, sr, sc, half_patch, n, d_keys_ref, d_pt_predict_un, d_status, d_affine, m, d_keys_cur,
+                                 d_keys_cur_un, level, radius_unit, use_ncc, 0, cap, d_count, d_nbr_idx, d_nbr_dist,
+                                 d_nbr_ncc);
+}
+
+// host-buffer forms: both frames go through the scratch slots (level 0 only), the per-feature arrays through one
+// device block; synchronous
+static int neighbors_host(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                          const float *keys_ref, const float *pt_predict_un, const uint8_t *status, const float *affine,
+                          int32_t m, const float *keys_cur, const float *keys_cur_un, int32_t level, float radius_unit,
+                          int32_t use_ncc, int32_t pairs, int32_t cap, int32_t *count, int32_t *nbr_idx, float *nbr_dist,
+                          float *nbr_ncc)
+{
+    int rc;
+    if ((rc = check_image(ref)) || (rc = check_image(cur))) return rc;
+    if ((rc = frame_upload_any(ctx, 4, ref, 1)) || (rc = frame_upload_any(ctx, 5, cur, 1))) return rc;
+    const size_t nn = (size_t)(n < 1 ? 1 : n), mm = (size_t)(m < 1 ? 1 : m), cc = (size_t)cap;
+    size_t off[11], total = 0;
+    const size_t sizes[11] = {nn * 8, nn * 8, nn, nn * 16, mm * 8, mm * 8, nn * 4, nn * cc * 4, nn * cc * 4, nn * cc * 4, 0};
+    for (int k = 0; k < 11; k++) {
+        off[k] = total;
+        total = align_up(total + sizes[k], 256);
+    }
+    if (total > ctx->score.bytes) {
+        if (ctx->score.block) HIPCHK(ctx, hipFree(ctx->score.block));
+        ctx->score.block = nullptr;
+        ctx->score.bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->score.block, total));
+        ctx->score.bytes = total;
+    }
+    uint8_t *b = static_cast<uint8_t *>(ctx->score.block);
+    auto up = [&](int k, const void *src, size_t bytes) -> int {
+        if (src && bytes) HIPCHK(ctx, hipMemcpyAsync(b + off[k], src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PAGK_OK;
+    };
+    if (n > 0) {
+        if ((rc = up(0, keys_ref, (size_t)n * 8)) || (rc = up(1, pt_predict_un, (size_t)n * 8)) ||
+            (rc = up(2, status, (size_t)n)) || (rc = up(3, affine, (size_t)n * 16)) || (rc = up(6, count, (size_t)n * 4)))
+            return rc;
+    }
+    if (m > 0 && ((rc = up(4, keys_cur, (size_t)m * 8)) || (rc = up(5, keys_cur_un, (size_t)m * 8)))) return rc;
+    rc = near_neighbors_launch(ctx, ctx->slots[4], ctx->slots[5], half_patch, n, reinterpret_cast<float *>(b + off[0]),
+                               reinterpret_cast<float *>(b + off[1]), b + off[2],
+                               affine ? reinterpret_cast<float *>(b + off[3]) : nullptr, m,
+                               reinterpret_cast<float *>(b + off[4]), reinterpret_cast<float *>(b + off[5]), level,
+                               radius_unit, use_ncc, pairs, cap, reinterpret_cast<int32_t *>(b + off[6]),
+                               reinterpret_cast<int32_t *>(b + off[7]), reinterpret_cast<float *>(b + off[8]),
+                               reinterpret_cast<float *>(b + off[9]));
+    if (rc) return rc;
+    if (n > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(count, b + off[6], (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (nbr_idx) HIPCHK(ctx, hipMemcpyAsync(nbr_idx, b + off[7], (size_t)n * cc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (nbr_dist) HIPCHK(ctx, hipMemcpyAsync(nbr_dist, b + off[8], (size_t)n * cc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(nbr_ncc, b + off[9], (size_t)n * cc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
+}
+
+int pagk_find_near_neighbors(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                             const float *keys_ref, const float *pt_predict_un, const uint8_t *status,
+                             const float *affine, int32_t m, const float *keys_cur, const float *keys_cur_un,
+                             int32_t level, float radius_unit, int32_t use_ncc, int32_t cap, int32_t *count,
+                             int32_t *nbr_idx, float *nbr_dist, float *nbr_ncc)
+{
+    if (!ctx) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_find_near_neighbors");
+    if (half_patch < 1 || half_patch > PAGK_MAX_HALF_PATCH || n < 0 || m < 0 || cap < 1 || level < 0) return PAGK_E_ARG;
+    if (n > 0 && (!keys_ref || !pt_predict_un || !status || !count || !nbr_idx || !nbr_dist || !nbr_ncc)) return PAGK_E_ARG;
+    if (n > 0 && m > 0 && (!keys_cur || !keys_cur_un)) return PAGK_E_ARG;
+    int rc = neighbors_host(ctx, ref, cur, half_patch, n, keys_ref, pt_predict_un, status, affine, m, keys_cur, keys_cur_un,
+                            level, radius_unit, use_ncc, 0, cap, count, nbr_idx, nbr_dist, nbr_ncc);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++)
+        if (count[i] > cap) {
+            snprintf(ctx->err, sizeof(ctx->err), "feature %d has %d neighbours, capacity is %d", i, count[i], cap);
+            return PAGK_E_CAPACITY;
+        }
+    return PAGK_OK;
+}
+
+int pagk_ncc_free(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, int32_t half_patch, int32_t n,
+                  const float *pt_ref, const float *pt_cur, const float *affine, float *ncc)
+{
+    if (!ctx) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_ncc_free");
+    if (half_patch < 1 || half_patch > PAGK_MAX_HALF_PATCH || n < 0) return PAGK_E_ARG;
+    if (n > 0 && (!pt_ref || !pt_cur || !ncc)) return PAGK_E_ARG;
+    if (n == 0) return PAGK_OK;
+    try {
+        std::vector<uint8_t> st((size_t)n, 1);
+        std::vector<int32_t> cnt((size_t)n, 0);
+        // pairs mode: feature i's only candidate is point i of pt_cur; capacity 1
+        return neighbors_host(ctx, ref, cur, half_patch, n, pt_ref, pt_ref, st.data(), affine, n, pt_cur, pt_cur, 0, 0.0f, 1, 1,
+                              1, cnt.data(), nullptr, nullptr, ncc);
+    } catch (const std::bad_alloc &) {
+        return PAGK_E_NOMEM;
+    }
+}
+
+// GyroAidedTracker::MatchFeatures, src/gyro_aided_tracker.cpp:949-1008.  Host-side: a sequential pass whose
+// decisions depend on the matches accepted so far.
+int pagk_match_features(int32_t n, int32_t cap, const int32_t *count, const int32_t *nbr_idx, const float *nbr_dist,
+                        const float *nbr_ncc, int32_t use_ncc, int32_t *match_query, int32_t *match_train,
+                        float *match_dist, float *match_ncc)
+{
+    if (n < 0 || cap < 1) return PAGK_E_ARG;
+    if (n > 0 && (!count || !nbr_idx || !nbr_dist || !nbr_ncc || !match_query || !match_train)) return PAGK_E_ARG;
+    const float TH_NCC_HIGH = 0.6f, TH_NCC_LOW = 0.3f, TH_RATIO = 0.75f;  // :7-9
+    struct M {
+        int q, t;
+        float d, c;
+    };
+    try {
+        std::vector<M> matches;
+        std::vector<int> found;  // sFoundInCurPts (:951): indices stay in it after their matches are erased
+        for (int i = 0; i < n; i++) {
+            const int c = count[i];
+            if (c <= 0) continue;  // :955
+            if (c > cap) return PAGK_E_CAPACITY;
+            const float *ncc = nbr_ncc + (size_t)i * cap, *dist = nbr_dist + (size_t)i * cap;
+            if (use_ncc) {  // :959-975
+                if (!(ncc[0] > TH_NCC_HIGH)) {
+                    if (c > 1) {
+                        if (ncc[0] < TH_NCC_LOW) continue;
+                        if (!(ncc[1] < ncc[0] * TH_RATIO)) continue;  // the two best are too similar
+                    } else
+                        continue;
+                }
+            } else if (c > 1 && !(dist[0] < dist[1] * TH_RATIO)) {  // :977-989
+                continue;
+            }
+            const M m{i, nbr_idx[(size_t)i * cap], dist[0], ncc[0]};
+            bool seen = false;
+            for (int t : found) seen = seen || t == m.t;
+            if (!seen) {  // :991-994
+                matches.push_back(m);
+                found.push_back(m.t);
+            } else {      // :995-1005
+                size_t w = 0;
+                for (size_t r = 0; r < matches.size(); r++)
+                    if (matches[r].t != m.t) matches[w++] = matches[r];
+                matches.resize(w);
+            }
+        }
+        for (size_t k = 0; k < matches.size(); k++) {
+            match_query[k] = matches[k].q;
+            match_train[k] = matches[k].t;
+            if (match_dist) match_dist[k] = matches[k].d;
+            if (match_ncc) match_ncc[k] = matches[k].c;
+        }
+        return (int)matches.size();
+    } catch (const std::bad_alloc &) {
         return PAGK_E_NOMEM;
     }
 }

@@ -918,3 +918,4 @@ __global__ void __launch_bounds__(256, 1) k_track_block_pyr(TrackArgs a, PyrArgs
 
 #include "pagk_wave_kernel.h"
 #include "pagk_score_kernel.h"
+#include "pagk_neighbor_kernel.h"

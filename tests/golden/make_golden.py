@@ -112,7 +112,55 @@ def main_geometry():
               f"choose {'H' if orc.geometry_select(sH, sF) else 'F'} validated {cnt}")
 
 
+def main_neighbors():
+    """NCC nearest-neighbour matching (reference src/gyro_aided_tracker.cpp:788-851, 949-1008; free NCC
+    src/utils.cpp:110-148): oracle outputs on seeded cases (tests/util.make_neighbor_case)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from util import NBR_DIR, make_neighbor_case
+    os.makedirs(NBR_DIR, exist_ok=True)
+    cases = {
+        "h5_ncc": (make_neighbor_case(0x4E420001), dict(use_ncc=True)),
+        "h5_distance": (make_neighbor_case(0x4E420002), dict(use_ncc=False)),
+        "h10_ncc": (make_neighbor_case(0x4E420003, half_patch=10), dict(use_ncc=True)),
+        "h5_noaffine": (make_neighbor_case(0x4E420004), dict(use_ncc=True, affine=False)),
+        "h5_pad1": (make_neighbor_case(0x4E420005, pad=1), dict(use_ncc=True)),
+        "h5_pad3": (make_neighbor_case(0x4E420006, pad=3), dict(use_ncc=True)),
+    }
+    for name, (g, opt) in cases.items():
+        h = int(g["half_patch"])
+        aff = g["affine"] if opt.get("affine", True) else None
+        cap = 48
+        # level 1, then level 2 for the features level 1 left empty (:912-925)
+        r1 = orc.find_near_neighbors(g["img_ref"], g["img_cur"], h, g["keys_ref"], g["pt_predict_un"], g["status"], aff,
+                                     g["keys_cur"], g["keys_cur_un"], level=1, use_ncc=opt["use_ncc"], cap=cap)
+        r2 = orc.find_near_neighbors(g["img_ref"], g["img_cur"], h, g["keys_ref"], g["pt_predict_un"], g["status"], aff,
+                                     g["keys_cur"], g["keys_cur_un"], level=2, use_ncc=opt["use_ncc"], cap=cap,
+                                     count=r1["count"])
+        assert r1["rc"] == 0 and r2["rc"] == 0
+        # level-2 lists of the features level 1 had already filled are not rewritten: merge like mvvNearNeighbors
+        keep = r1["count"] > 0
+        for k in ("idx", "dist", "ncc"):
+            r2[k][keep] = r1[k][keep]
+        m1 = orc.match_features(r1["count"], r1["idx"], r1["dist"], r1["ncc"], opt["use_ncc"])
+        m2 = orc.match_features(r2["count"], r2["idx"], r2["dist"], r2["ncc"], opt["use_ncc"])
+        step = g["img_ref"].strides[0]
+        np.savez_compressed(
+            os.path.join(NBR_DIR, name + ".npz"),
+            **{k: (np.ascontiguousarray(v) if getattr(v, "ndim", 0) > 0 else v) for k, v in g.items()},
+            row_step=np.int32(step), use_ncc=np.int32(opt["use_ncc"]), use_affine=np.int32(opt.get("affine", True)),
+            cap=np.int32(cap),
+            out1_count=r1["count"], out1_idx=r1["idx"], out1_dist=r1["dist"], out1_ncc=r1["ncc"],
+            out2_count=r2["count"], out2_idx=r2["idx"], out2_dist=r2["dist"], out2_ncc=r2["ncc"],
+            match1_query=m1[0], match1_train=m1[1], match2_query=m2[0], match2_train=m2[1])
+        print(f"neighbors/{name}: n={g['keys_ref'].shape[0]} m={g['keys_cur'].shape[0]} lists l1 {int((r1['count']>0).sum())} "
+              f"(max {int(r1['count'].max())}) l2 {int((r2['count']>0).sum())} (max {int(r2['count'].max())}) "
+              f"matches {len(m1[0])} / {len(m2[0])}")
+
+
 if __name__ == "__main__":
-    if "--geometry-only" not in sys.argv:
+    if "--geometry-only" not in sys.argv and "--neighbors-only" not in sys.argv:
         main()
-    main_geometry()
+    if "--neighbors-only" not in sys.argv:
+        main_geometry()
+    if "--geometry-only" not in sys.argv:
+        main_neighbors()

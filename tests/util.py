@@ -94,3 +94,72 @@ def make_geometry_case(seed, n, outlier_fraction=0.1, noise_px=0.4, planar=False
     c = np.ascontiguousarray   # (K @ X).T arithmetic leaves column-major arrays behind
     return dict(H21=c(H21), H12=c(np.linalg.inv(H21)), F21=c(F21), pts1=c(uv1, np.float32), pts2=c(uv2, np.float32),
                 sigma=np.float32(1.0))
+
+
+# ---- NCC nearest-neighbour matching cases ------------------------------
+NBR_DIR = os.path.join(GOLDEN_DIR, "neighbors")
+
+
+def neighbor_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(NBR_DIR, "*.npz")))
+
+
+def load_neighbors(name):
+    z = np.load(os.path.join(NBR_DIR, name + ".npz"), allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    step = int(g["row_step"])
+    for k in ("img_ref", "img_cur"):   # restore the row stride of the non-continuous cases (padding bytes = 0)
+        img = g[k]
+        if step != img.shape[1]:
+            buf = np.zeros((img.shape[0], step), np.uint8)
+            buf[:, :img.shape[1]] = img
+            g[k] = buf[:, :img.shape[1]]
+    return g
+
+
+def make_neighbor_case(seed, n=64, width=320, height=240, half_patch=5, clutter=24, pad=0, border=True):
+    """Inputs of FindAndSortNearNeighbor (reference src/gyro_aided_tracker.cpp:788-851) on a seeded synthetic
+    pair: reference keypoints with their predictions and affines (synth), and a set of 'detected' current
+    keypoints -- the true positions with detection noise, a second detection next to some of them (ratio test),
+    exact duplicates (equal scores: insertion order decides) and clutter.  Distorted and undistorted current
+    keypoints differ, as in the reference (mvKeysCur vs mvKeysCurUn).  `border`: integer-coordinate keypoints
+    whose patches touch x == cols / y == rows (the free sampler's `>` clamp).  `pad`: extra bytes per image row
+    (non-continuous cv::Mat).  Inputs only: expected outputs always come from the oracle."""
+    rng = np.random.default_rng(seed)
+    w = synth.make_workload("nbr", width, height, n, seed=seed, half_patch=half_patch, iterations=10, pyramids=3,
+                            camera=synth.D435I, omega=(0.2, -0.3, 0.8))
+    h = half_patch
+    keys_ref = w.pt_ref.copy()
+    pred = w.pt_init.copy()
+    status = w.status_in.copy()
+    affine = w.affine.copy()
+    if border:   # patches that reach column `cols` and row `rows` exactly, and the image corner
+        for k, (x, y) in enumerate([(width - h, height // 2), (width // 2, height - h), (width - h, height - h),
+                                    (float(h) - 0.5, float(h) - 0.5)]):
+            keys_ref[k] = (x, y)
+            pred[k] = (min(x, width - h - 1), min(y, height - h - 1))
+            status[k] = 1
+    det_un = pred + rng.normal(0, 1.5, pred.shape)
+    det_un[3::7] += (2.6 * h, -2.4 * h)   # predictions that are off by more than the level-1 radius (2h): level 2 finds them
+    second = pred[::3] + rng.normal(0, 4.0, pred[::3].shape)
+    dup = det_un[5:15].copy()                                   # exact duplicates of earlier detections
+    clut = np.c_[rng.uniform(0, width, clutter), rng.uniform(0, height, clutter)]
+    keys_cur_un = np.concatenate([det_un, second, dup, clut]).astype(np.float32)
+    # "distorted" detections: a smooth deterministic displacement (stand-in for the camera's distortion)
+    cx, cy = width / 2.0, height / 2.0
+    r2 = ((keys_cur_un[:, 0] - cx) ** 2 + (keys_cur_un[:, 1] - cy) ** 2) / (cx * cx + cy * cy)
+    keys_cur = (keys_cur_un + 0.8 * r2[:, None] * (keys_cur_un - np.array([cx, cy], np.float32))).astype(np.float32)
+    if border:   # a detection whose warped patch crosses the right / bottom edge
+        keys_cur[0] = (width - h + 0.25, height - h)
+    perm = rng.permutation(keys_cur.shape[0])
+    keys_cur, keys_cur_un = np.ascontiguousarray(keys_cur[perm]), np.ascontiguousarray(keys_cur_un[perm])
+
+    def padded(img):
+        if pad == 0:
+            return np.ascontiguousarray(img)
+        buf = np.full((img.shape[0], img.shape[1] + pad), 0, np.uint8)   # padding bytes are defined as 0
+        buf[:, :img.shape[1]] = img
+        return buf[:, :img.shape[1]]
+    return dict(img_ref=padded(w.img_ref), img_cur=padded(w.img_cur), half_patch=np.int32(h),
+                keys_ref=keys_ref.astype(np.float32), pt_predict_un=pred.astype(np.float32), status=status,
+                affine=affine.astype(np.float32), keys_cur=keys_cur, keys_cur_un=keys_cur_un)

@@ -1,4 +1,5 @@
-"""A/B two builds of libpagk_hip.so in one process run each, alternating: python tools/ab_lib.py <libB.so>"""
+"""A/B two builds of libpagk_hip.so in one process run each, alternating: python tools/ab_lib.py <libB.so> ...
+PAGK_AB_CASES="cfg:n:kernel,..." chooses the launches (default 1:1000:0,1:4000:0,3:20000:0)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 child = r'''
@@ -10,8 +11,10 @@ if sys.argv[1] != "-":
     capi.LIB_PATH = sys.argv[1]
 ctx = capi.Context(0)
 out = []
-for cfg, n, kern in ((1, 1000, 0), (1, 4000, 0), (3, 20000, 0)):
+cases = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("PAGK_AB_CASES", "1:1000:0,1:4000:0,3:20000:0").split(",")]
+for cfg, n, kern in cases:
     w = synth.config(cfg, n=n)
+    ctx.set_kernel(kern)
     p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
     ts = []
     for _ in range(16):

@@ -32,3 +32,13 @@ for k in (0, 1, 2, 3, 5):
           + (f", {per_it.mean():7.0f} cyc/iteration" if k in (1, 2, 3) else ""))
 tb = d[:, 7]
 print(f"  block start spread: {(tb.max()-tb.min())/100:.1f} us (100 MHz ticks?) raw {tb.max()-tb.min():.0f}; block duration mean {d[:,5].mean():.0f} max {d[:,5].max():.0f} cycles")
+# schedule of the launch: when each workgroup started / finished relative to the first start (cycles)
+t0 = tb.min()
+start, end = tb - t0, tb - t0 + d[:, 5]
+late = start > 0.05 * end.max()
+print(f"  launch span {end.max():.0f} cycles; workgroups starting later than 5% of the span: {int(late.sum())} "
+      f"(their start: mean {start[late].mean() if late.any() else 0:.0f}, max {start.max():.0f})")
+order = np.argsort(end)
+print("  last 5 finishers: " + ", ".join(f"iters {int(it[k])} start {start[k]:.0f} end {end[k]:.0f}" for k in order[-5:]))
+for q in (50, 90, 99, 100):
+    print(f"  iters p{q}: {np.percentile(it, q):.0f}   end p{q}: {np.percentile(end, q):.0f}")
