@@ -1230,6 +1230,10 @@ static int neighbors_host(pagk_ctx *ctx, const pagk_image *ref, const pagk_image
             return rc;
     }
     if (m > 0 && ((rc = up(4, keys_cur, (size_t)m * 8)) || (rc = up(5, keys_cur_un, (size_t)m * 8)))) return rc;
+    // the lists of skipped features (status 0, or already filled at a smaller radius) keep the caller's content
+    if (!pairs && n > 0 && ((rc = up(7, nbr_idx, (size_t)n * cc * 4)) || (rc = up(8, nbr_dist, (size_t)n * cc * 4)) ||
+                            (rc = up(9, nbr_ncc, (size_t)n * cc * 4))))
+        return rc;
     rc = near_neighbors_launch(ctx, ctx->slots[4], ctx->slots[5], half_patch, n, reinterpret_cast<float *>(b + off[0]),
                                reinterpret_cast<float *>(b + off[1]), b + off[2],
                                affine ? reinterpret_cast<float *>(b + off[3]) : nullptr, m,

@@ -133,7 +133,16 @@ __device__ __forceinline__ void pyr_emit(const PyrArgs &a, int idx)
         }
         return rr < rows ? pyr_pixel<L>(a.src, a.pitch, rr, cc) : 0u;
     };
-    const uint32_t d0 = px(r, c), d1 = px(r, c + 1), d2 = px(r + 1, c), d3 = px(r + 1, c + 1);
+    // the four taps one after the other (a scheduling fence between them at the coarse levels): issued all at
+    // once, the 4 x 4^L byte loads of a level-2/3 pixel cost ~40 VGPRs, and these blocks share their register
+    // allocation with the tracking workgroups of k_track_block_pyr, whose occupancy they must not lower
+    const uint32_t d0 = px(r, c);
+    if constexpr (L >= 2) asm volatile("" ::: "memory");
+    const uint32_t d1 = px(r, c + 1);
+    if constexpr (L >= 2) asm volatile("" ::: "memory");
+    const uint32_t d2 = px(r + 1, c);
+    if constexpr (L >= 2) asm volatile("" ::: "memory");
+    const uint32_t d3 = px(r + 1, c + 1);
     a.quad[L][idx] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
     if constexpr (L > 0) a.u8[L][idx] = (uint8_t)d0;
 }
@@ -894,8 +903,11 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #undef STAMP
 }
 
+// second argument = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs).  For the 4-wave kernel that is
+// four workgroups per CU, i.e. all 1000 features of BASELINE configs[1] resident at once on 256 CUs (checked against
+// the code object by __graft_entry__.build()).
 template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
-__global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackArgs a)
+__global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
 {
     track_block_body<NR, TAIL, WAVES, MFMA, RELAXED>(a);
 }
@@ -905,7 +917,7 @@ __global__ void __launch_bounds__(WAVES * 64, MFMA ? 4 : 1) k_track_block(TrackA
 // pipelines that already hold frame k+1 while pair (k-1, k) is tracked (replays, or a camera loop that accepts
 // one frame of latency): the pyramid then costs no launch of its own and runs in the tracking launch's shadow.
 template <int NR, int TAIL>
-__global__ void __launch_bounds__(256, 1) k_track_block_pyr(TrackArgs a, PyrArgs pa)
+__global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs pa)
 {
     if ((int)blockIdx.x >= a.n) {
         pyr_block(pa, (int)blockIdx.x - a.n, (int)threadIdx.x);
