@@ -172,7 +172,9 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  * bit-identical results.
  * 4 = EXPERIMENT, never chosen automatically: the 4-wave kernel with the reference's summation order
  *     given up (strided partial sums + tree instead of the 441-step ordered chains).  Not parity-exact:
- *     it exists to measure what the ordered accumulation costs. */
+ *     it exists to measure what the ordered accumulation costs.
+ * 5 = four features per wavefront (block q of the f64 MFMA, row q of the cost chain and lane = feature solve shared
+ *     by four features): the highest-throughput variant for very large launches; bit-identical like 0-3. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 
 /* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,
@@ -292,6 +294,43 @@ int pagk_ncc_free(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, i
 int pagk_match_features(int32_t n, int32_t cap, const int32_t *count, const int32_t *nbr_idx, const float *nbr_dist,
                         const float *nbr_ncc, int32_t use_ncc, int32_t *match_query, int32_t *match_train,
                         float *match_dist, float *match_ncc);
+
+/* ---- the path sharded over the GPUs of one node ---------------------- */
+/* Features are independent units (the cv::parallel_for_ of src/patch_match.cpp:103), so the path shards by
+ * contiguous index blocks of ceil(n / G) features: rank r owns [r * ceil(n/G), min(n, (r+1) * ceil(n/G))).  Every
+ * GPU holds both pyramids; the only exchange is ONE all-gather (RCCL ncclAllGather over xGMI) of the packed
+ * per-rank result slice, after which every rank holds every result and the tracker's global post-filter
+ * (src/gyro_aided_tracker.cpp:289-341) runs on them in index order.  The library owns the RCCL communicator
+ * (loaded with dlopen on first use); failures of RCCL calls return PAGK_E_NCCL. */
+typedef struct pagk_multi pagk_multi;
+/* One process driving n_devices GPUs (a C++ GyroAidedTracker host): one context and one RCCL rank per device
+ * (ncclCommInitAll).  n_devices = 1 is a valid group. */
+int pagk_multi_create(pagk_multi **out, const int32_t *devices, int32_t n_devices);
+/* One process per GPU (e.g. under torchrun): rank 0 calls pagk_multi_unique_id, the host application hands the 128
+ * bytes to every rank through its own channel, each rank joins with its device (ncclCommInitRank). */
+int pagk_multi_unique_id(uint8_t id[128]);
+int pagk_multi_create_rank(pagk_multi **out, const uint8_t id[128], int32_t rank, int32_t world, int32_t device);
+void pagk_multi_destroy(pagk_multi *pm);
+int32_t pagk_multi_world(const pagk_multi *pm);  /* ranks of the group                        */
+int32_t pagk_multi_local(const pagk_multi *pm);  /* ranks driven by this process              */
+pagk_ctx *pagk_multi_ctx(pagk_multi *pm, int32_t local_index);  /* owned by the group; do not pagk_destroy */
+const char *pagk_multi_last_error(const pagk_multi *pm);
+/* The partition and the layout of a rank's packed result slice for m = ceil(n / G) features: seven SoA blocks in
+ * SetMatcher order (pt_un, pt_dist, status, pix_err, dist_pred, ncc, iters), each padded to 8 bytes; returns the
+ * slice size in bytes. */
+void pagk_shard_range(int32_t n, int32_t rank, int32_t world, int32_t *lo, int32_t *hi);
+size_t pagk_shard_layout(int32_t m, size_t offsets[7]);
+/* The exchange: every local member k contributes `bytes` bytes at d_send[k] and receives world * bytes at
+ * d_recv[k], in rank order, on its context's stream (hip_streams: NULL, or one stream per local member).
+ * Asynchronous; ordered on the stream after the tracking launch that produced the slice. */
+int pagk_multi_allgather(pagk_multi *pm, const void *const *d_send, void *const *d_recv, size_t bytes,
+                         void *const *hip_streams);
+/* pagk_track with the feature loop split over the group (single-process groups): same arguments, same results
+ * bit for bit.  Every GPU uploads both frames and builds both pyramids, tracks its block, the packed slices are
+ * all-gathered, the host reads the gathered result from member 0.  Synchronous. */
+int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_image *ref, const pagk_image *cur,
+                       int32_t n, const float *pt_ref_un, const float *pt_init_un, const float *affine,
+                       const uint8_t *status_in, const pagk_outputs *out);
 
 #ifdef __cplusplus
 }

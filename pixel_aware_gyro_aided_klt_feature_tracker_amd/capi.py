@@ -193,6 +193,31 @@ def declare(lib) -> None:
     lib.pagk_ncc_free.argtypes = [vp, _P(Image), _P(Image), i32, i32, vp, vp, vp, vp]
     lib.pagk_match_features.restype = C.c_int
     lib.pagk_match_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    # the sharded path
+    lib.pagk_multi_create.restype = C.c_int
+    lib.pagk_multi_create.argtypes = [_P(vp), _P(i32), i32]
+    lib.pagk_multi_unique_id.restype = C.c_int
+    lib.pagk_multi_unique_id.argtypes = [vp]
+    lib.pagk_multi_create_rank.restype = C.c_int
+    lib.pagk_multi_create_rank.argtypes = [_P(vp), vp, i32, i32, i32]
+    lib.pagk_multi_destroy.restype = None
+    lib.pagk_multi_destroy.argtypes = [vp]
+    lib.pagk_multi_world.restype = i32
+    lib.pagk_multi_world.argtypes = [vp]
+    lib.pagk_multi_local.restype = i32
+    lib.pagk_multi_local.argtypes = [vp]
+    lib.pagk_multi_ctx.restype = vp
+    lib.pagk_multi_ctx.argtypes = [vp, i32]
+    lib.pagk_multi_last_error.restype = C.c_char_p
+    lib.pagk_multi_last_error.argtypes = [vp]
+    lib.pagk_shard_range.restype = None
+    lib.pagk_shard_range.argtypes = [i32, i32, i32, _P(i32), _P(i32)]
+    lib.pagk_shard_layout.restype = C.c_size_t
+    lib.pagk_shard_layout.argtypes = [i32, _P(C.c_size_t)]
+    lib.pagk_multi_allgather.restype = C.c_int
+    lib.pagk_multi_allgather.argtypes = [vp, _P(vp), _P(vp), C.c_size_t, _P(vp)]
+    lib.pagk_track_sharded.restype = C.c_int
+    lib.pagk_track_sharded.argtypes = [vp, _P(Params), _P(Image), _P(Image), i32, vp, vp, vp, vp, _P(Outputs)]
 
 
 EXPORTED_SYMBOLS = [
@@ -204,6 +229,9 @@ EXPORTED_SYMBOLS = [
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
     "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
     "pagk_near_neighbors_device", "pagk_find_near_neighbors", "pagk_ncc_free", "pagk_match_features",
+    "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
+    "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
+    "pagk_multi_allgather", "pagk_track_sharded",
 ]
 
 
@@ -231,8 +259,12 @@ class PagkError(RuntimeError):
 class Context:
     """pagk_ctx owner.  One per GPU / host thread."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         self.lib = load()
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # a member context of a Multi group: the group destroys it
+            self.h = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         rc = self.lib.pagk_create(C.byref(h), device)
         if rc != PAGK_OK:
@@ -241,7 +273,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.pagk_destroy(self.h)
+            if self._owned:
+                self.lib.pagk_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -474,3 +507,90 @@ def match_features(count, idx, dist, ncc, use_ncc=True):
     if k < 0:
         raise PagkError(k, "pagk_match_features")
     return q[:k], t[:k], d[:k], c[:k]
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """pagk_shard_range: the contiguous feature block of a rank."""
+    lo, hi = C.c_int32(0), C.c_int32(0)
+    load().pagk_shard_range(n, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def shard_layout(m: int) -> tuple[list[int], int]:
+    """pagk_shard_layout: byte offsets of the seven SoA blocks of a rank's packed slice, and its size."""
+    offs = (C.c_size_t * 7)()
+    total = load().pagk_shard_layout(m, offs)
+    return [int(v) for v in offs], int(total)
+
+
+class Multi:
+    """pagk_multi owner: the group of GPUs one tracking call is sharded over, and its RCCL communicator.
+    Multi(devices=[...]) drives all devices from this process; Multi(uid=..., rank=, world=, device=) joins a
+    one-process-per-GPU group (uid from Multi.unique_id() on rank 0, handed over by the application)."""
+
+    def __init__(self, devices=None, *, uid: bytes | None = None, rank: int = 0, world: int = 1, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        if uid is None:
+            devs = (C.c_int32 * len(devices))(*devices)
+            rc = self.lib.pagk_multi_create(C.byref(h), devs, len(devices))
+            where = "pagk_multi_create"
+        else:
+            if len(uid) != 128:
+                raise ValueError("the RCCL unique id is 128 bytes")
+            buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+            rc = self.lib.pagk_multi_create_rank(C.byref(h), buf, rank, world, device)
+            where = "pagk_multi_create_rank"
+        if rc != PAGK_OK:
+            raise PagkError(rc, where)
+        self.h = h
+        self.world = self.lib.pagk_multi_world(h)
+        self.n_local = self.lib.pagk_multi_local(h)
+        self.rank = rank if uid is not None else 0
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = load().pagk_multi_unique_id(buf)
+        if rc != PAGK_OK:
+            raise PagkError(rc, "pagk_multi_unique_id")
+        return bytes(buf)
+
+    def ctx(self, local_index: int = 0) -> Context:
+        p = self.lib.pagk_multi_ctx(self.h, local_index)
+        if not p:
+            raise IndexError(local_index)
+        return Context(_borrowed=p)
+
+    def _check(self, rc: int, where: str):
+        if rc != PAGK_OK:
+            raise PagkError(rc, where, self.lib.pagk_multi_last_error(self.h).decode())
+
+    def allgather(self, d_send, d_recv, nbytes: int, streams=None):
+        """One all-gather of `nbytes` bytes per rank; d_send / d_recv: one device buffer per local member."""
+        k = self.n_local
+        snd = (C.c_void_p * k)(*[_ptr(a) for a in d_send])
+        rcv = (C.c_void_p * k)(*[_ptr(a) for a in d_recv])
+        st = None if streams is None else (C.c_void_p * k)(*streams)
+        self._check(self.lib.pagk_multi_allgather(self.h, snd, rcv, nbytes, st), "pagk_multi_allgather")
+
+    def track_sharded(self, params: Params, img_ref, img_cur, pt_ref, pt_init, affine, status_in, out: dict | None = None):
+        n = int(pt_ref.shape[0])
+        out = out if out is not None else alloc_outputs(n)
+        ir, ic = image_view(img_ref), image_view(img_cur)
+        o = outputs_struct(out)
+        self._check(self.lib.pagk_track_sharded(self.h, C.byref(params), C.byref(ir), C.byref(ic), n, _ptr(pt_ref),
+                                                _ptr(pt_init), _ptr(affine), _ptr(status_in), C.byref(o)),
+                    "pagk_track_sharded")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pagk_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

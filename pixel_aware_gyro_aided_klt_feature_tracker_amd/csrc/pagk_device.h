@@ -95,45 +95,98 @@ __device__ __forceinline__ float bilerp(uint32_t q, const Coord &cx, const Coord
     return cy.omf * top + cy.f * bot;
 }
 
+// ---- packed-f32 form of the sampler (PAGK_PK_BILERP), optionally with typed tap loads (PAGK_TYPED_TAPS) --------
+typedef float pagk_f32x4 __attribute__((ext_vector_type(4)));
+typedef float pagk_f32x2 __attribute__((ext_vector_type(2)));
+typedef int pagk_i32x4 __attribute__((ext_vector_type(4)));
+
 #ifdef PAGK_TYPED_TAPS
 // The four taps of a quad arrive as four floats: the texture addresser converts them.  A quad dword is read
 // through a buffer resource whose element format is 8_8_8_8 / USCALED (unsigned byte -> float, exact), so
 // `buffer_load_format_xyzw` returns (float)byte0..3 and the 4 x v_cvt_f32_ubyte per sample disappear from the
-// VALU stream; `idxen` with a 4-byte stride takes the element index as is (no 64-bit address arithmetic).
-// clang has no builtin for the format loads; the LLVM intrinsic is reached through its asm label.
-typedef float pagk_f32x4 __attribute__((ext_vector_type(4)));
-typedef int pagk_i32x4 __attribute__((ext_vector_type(4)));
+// VALU stream; `idxen` with a 4-byte stride takes the element index as is (no 64-bit address arithmetic).  The
+// destination swizzle delivers (d0, d2 | d1, d3).  clang has no builtin for the format loads; the LLVM intrinsic is
+// reached through its asm label.  Bit-identical to the byte unpacking on MI355X (the parity suite runs through it).
+// Price: 16 bytes per lane come back from the texture unit instead of 4, and 4 VGPRs per tap in flight.
 __device__ pagk_f32x4 pagk_buffer_load_format_xyzw(pagk_i32x4 rsrc, int vindex, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.struct.buffer.load.format.v4f32");
 
-__device__ __forceinline__ pagk_i32x4 tap_rsrc(const DevLevel &L)
+struct TapSrc {
+    pagk_i32x4 rs;
+};
+__device__ __forceinline__ TapSrc tap_src(const DevLevel &L)
 {
     const uint64_t base = (uint64_t)(uintptr_t)L.quad;
-    pagk_i32x4 r;
-    r.x = (int)(uint32_t)base;
-    r.y = (int)((uint32_t)(base >> 32) & 0xffffu) | (4 << 16);  // stride 4 bytes
-    r.z = L.cols * L.rows;                                       // records
-    // dst_sel x,y,z,w = R,G,B,A; num_format USCALED (2); data_format 8_8_8_8 (10)
-    r.w = 4 | (5 << 3) | (6 << 6) | (7 << 9) | (2 << 12) | (10 << 15);
-    return r;
+    TapSrc t;
+    t.rs.x = (int)(uint32_t)base;
+    t.rs.y = (int)((uint32_t)(base >> 32) & 0xffffu) | (4 << 16);  // stride 4 bytes
+    t.rs.z = L.cols * L.rows;                                       // records
+    // dst_sel x,y,z,w = byte0 (R), byte2 (B), byte1 (G), byte3 (A); num_format USCALED (2); data_format 8_8_8_8 (10)
+    t.rs.w = 4 | (6 << 3) | (5 << 6) | (7 << 9) | (2 << 12) | (10 << 15);
+    return t;
 }
-
-__device__ __forceinline__ float bilerp4(pagk_f32x4 d, const Coord &cx, const Coord &cy)
+typedef pagk_f32x4 Taps;   // (d0, d2, d1, d3) as floats
+__device__ __forceinline__ Taps load_taps(const TapSrc &t, int idx) { return pagk_buffer_load_format_xyzw(t.rs, idx, 0, 0, 0); }
+__device__ __forceinline__ pagk_f32x4 taps_f32(Taps q) { return q; }
+#else
+struct TapSrc {
+    const uint32_t *quad;
+};
+__device__ __forceinline__ TapSrc tap_src(const DevLevel &L) { return TapSrc{L.quad}; }
+typedef uint32_t Taps;     // the packed quad dword; converted when consumed
+// unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
+__device__ __forceinline__ Taps load_taps(const TapSrc &t, int idx) { return t.quad[(uint32_t)idx]; }
+__device__ __forceinline__ pagk_f32x4 taps_f32(Taps q)
 {
-    float top = cx.omf * d.x + cx.f * d.y;
-    float bot = cx.omf * d.z + cx.f * d.w;
-    return cy.omf * top + cy.f * bot;
+    pagk_f32x4 d;   // (d0, d2, d1, d3): v_cvt_f32_ubyte0/2/1/3 straight into the two register pairs
+    d.x = (float)(q & 0xffu);
+    d.y = (float)((q >> 16) & 0xffu);
+    d.z = (float)((q >> 8) & 0xffu);
+    d.w = (float)(q >> 24);
+    return d;
 }
 #endif
+
+// b*(a*d0 + xx*d1) + yy*(a*d2 + xx*d3) (:402-403) on the pairs (d0, d2), (d1, d3): the same seven roundings in
+// the same association, the two rows of the quad side by side in v_pk_mul_f32 / v_pk_add_f32 (IEEE per component,
+// no contraction).  cx = (a, xx) = (1 - xx, xx) of the x coordinate, cy = (b, yy) of the y coordinate.
+__device__ __forceinline__ float bilerp_pk(pagk_f32x4 d, pagk_f32x2 cx, pagk_f32x2 cy)
+{
+    const pagk_f32x2 rows = d.xy * cx.xx + d.zw * cx.yy;  // (a*d0 + xx*d1, a*d2 + xx*d3)
+    const pagk_f32x2 t = rows * cy;                       // (b*top, yy*bot)
+    return t.x + t.y;
+}
+
+struct CoordPk {
+    int i;            // int(x)
+    pagk_f32x2 w;     // (1 - xx, xx)
+};
+
+template <bool CLAMP>
+__device__ __forceinline__ CoordPk prep_coord_pk(float x, float fmax, float fmax_m1)
+{
+    if (CLAMP) {
+        x = fmaxf(x, 0.0f);
+        x = (x >= fmax) ? fmax_m1 : x;
+    }
+    CoordPk c;
+    c.i = (int)x;
+    const float f = __builtin_amdgcn_fractf(x);
+    c.w.y = f;
+    c.w.x = 1.0f - f;
+    return c;
+}
 
 template <bool CLAMP>
 __device__ __forceinline__ float sample(const DevLevel &L, float x, float y)
 {
+#ifdef PAGK_PK_BILERP
+    const CoordPk cx = prep_coord_pk<CLAMP>(x, L.fcols, L.fcols_m1);
+    const CoordPk cy = prep_coord_pk<CLAMP>(y, L.frows, L.frows_m1);
+    return bilerp_pk(taps_f32(load_taps(tap_src(L), __mul24(cy.i, L.cols) + cx.i)), cx.w, cy.w);
+#else
     Coord cx = prep_coord<CLAMP>(x, L.fcols, L.fcols_m1);
     Coord cy = prep_coord<CLAMP>(y, L.frows, L.frows_m1);
-#ifdef PAGK_TYPED_TAPS
-    return bilerp4(pagk_buffer_load_format_xyzw(tap_rsrc(L), __mul24(cy.i, L.cols) + cx.i, 0, 0, 0), cx, cy);
-#else
     return bilerp(L.quad[(uint32_t)(__mul24(cy.i, L.cols) + cx.i)], cx, cy);
 #endif
 }
@@ -144,45 +197,86 @@ struct Five {
     float c, xp, xm, yp, ym;
 };
 
+// The same in two halves, so that a kernel can put other work (or a phase stamp) between the gathers and
+// their first use: sample5_issue computes the six coordinates and issues the five tap loads, sample5_finish
+// interpolates.
+#ifdef PAGK_PK_BILERP
+struct FiveTaps {
+    Taps q0, q1, q2, q3, q4;
+    pagk_f32x2 cx, cxp, cxm, cy, cyp, cym;
+};
+template <bool CLAMP>
+__device__ __forceinline__ FiveTaps sample5_issue(const DevLevel &L, float X, float Y)
+{
+    const CoordPk cx = prep_coord_pk<CLAMP>(X, L.fcols, L.fcols_m1);
+    const CoordPk cxp = prep_coord_pk<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
+    const CoordPk cxm = prep_coord_pk<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
+    const CoordPk cy = prep_coord_pk<CLAMP>(Y, L.frows, L.frows_m1);
+    const CoordPk cyp = prep_coord_pk<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
+    const CoordPk cym = prep_coord_pk<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
+    // row offsets: both factors are < 2^24 (checked at upload), full-rate 24-bit multiply-add
+    const int rc = __mul24(cy.i, L.cols), rp = __mul24(cyp.i, L.cols), rm = __mul24(cym.i, L.cols);
+    const TapSrc ts = tap_src(L);
+    FiveTaps t;
+    t.q0 = load_taps(ts, rc + cx.i);
+    t.q1 = load_taps(ts, rc + cxp.i);
+    t.q2 = load_taps(ts, rc + cxm.i);
+    t.q3 = load_taps(ts, rp + cx.i);
+    t.q4 = load_taps(ts, rm + cx.i);
+    t.cx = cx.w, t.cxp = cxp.w, t.cxm = cxm.w, t.cy = cy.w, t.cyp = cyp.w, t.cym = cym.w;
+    return t;
+}
+__device__ __forceinline__ Five sample5_finish(const FiveTaps &t)
+{
+    Five r;
+    r.c = bilerp_pk(taps_f32(t.q0), t.cx, t.cy);
+    r.xp = bilerp_pk(taps_f32(t.q1), t.cxp, t.cy);
+    r.xm = bilerp_pk(taps_f32(t.q2), t.cxm, t.cy);
+    r.yp = bilerp_pk(taps_f32(t.q3), t.cx, t.cyp);
+    r.ym = bilerp_pk(taps_f32(t.q4), t.cx, t.cym);
+    return r;
+}
+#else
+struct FiveTaps {
+    uint32_t q0, q1, q2, q3, q4;
+    Coord cx, cxp, cxm, cy, cyp, cym;
+};
+template <bool CLAMP>
+__device__ __forceinline__ FiveTaps sample5_issue(const DevLevel &L, float X, float Y)
+{
+    FiveTaps t;
+    t.cx = prep_coord<CLAMP>(X, L.fcols, L.fcols_m1);
+    t.cxp = prep_coord<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
+    t.cxm = prep_coord<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
+    t.cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
+    t.cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
+    t.cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
+    const int rc = __mul24(t.cy.i, L.cols), rp = __mul24(t.cyp.i, L.cols), rm = __mul24(t.cym.i, L.cols);
+    const uint32_t *q = L.quad;
+    // unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
+    t.q0 = q[(uint32_t)(rc + t.cx.i)];
+    t.q1 = q[(uint32_t)(rc + t.cxp.i)];
+    t.q2 = q[(uint32_t)(rc + t.cxm.i)];
+    t.q3 = q[(uint32_t)(rp + t.cx.i)];
+    t.q4 = q[(uint32_t)(rm + t.cx.i)];
+    return t;
+}
+__device__ __forceinline__ Five sample5_finish(const FiveTaps &t)
+{
+    Five r;
+    r.c = bilerp(t.q0, t.cx, t.cy);
+    r.xp = bilerp(t.q1, t.cxp, t.cy);
+    r.xm = bilerp(t.q2, t.cxm, t.cy);
+    r.yp = bilerp(t.q3, t.cx, t.cyp);
+    r.ym = bilerp(t.q4, t.cx, t.cym);
+    return r;
+}
+#endif
+
 template <bool CLAMP>
 __device__ __forceinline__ Five sample5(const DevLevel &L, float X, float Y)
 {
-    Coord cx = prep_coord<CLAMP>(X, L.fcols, L.fcols_m1);
-    Coord cxp = prep_coord<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
-    Coord cxm = prep_coord<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
-    Coord cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
-    Coord cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
-    Coord cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
-    // row offsets: both factors are < 2^24 (checked at upload), full-rate 24-bit multiply
-    int rc = __mul24(cy.i, L.cols), rp = __mul24(cyp.i, L.cols), rm = __mul24(cym.i, L.cols);
-    Five r;
-#ifdef PAGK_TYPED_TAPS
-    const pagk_i32x4 rs = tap_rsrc(L);
-    pagk_f32x4 q0 = pagk_buffer_load_format_xyzw(rs, rc + cx.i, 0, 0, 0);
-    pagk_f32x4 q1 = pagk_buffer_load_format_xyzw(rs, rc + cxp.i, 0, 0, 0);
-    pagk_f32x4 q2 = pagk_buffer_load_format_xyzw(rs, rc + cxm.i, 0, 0, 0);
-    pagk_f32x4 q3 = pagk_buffer_load_format_xyzw(rs, rp + cx.i, 0, 0, 0);
-    pagk_f32x4 q4 = pagk_buffer_load_format_xyzw(rs, rm + cx.i, 0, 0, 0);
-    r.c = bilerp4(q0, cx, cy);
-    r.xp = bilerp4(q1, cxp, cy);
-    r.xm = bilerp4(q2, cxm, cy);
-    r.yp = bilerp4(q3, cx, cyp);
-    r.ym = bilerp4(q4, cx, cym);
-#else
-    const uint32_t *q = L.quad;
-    // unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
-    uint32_t q0 = q[(uint32_t)(rc + cx.i)];
-    uint32_t q1 = q[(uint32_t)(rc + cxp.i)];
-    uint32_t q2 = q[(uint32_t)(rc + cxm.i)];
-    uint32_t q3 = q[(uint32_t)(rp + cx.i)];
-    uint32_t q4 = q[(uint32_t)(rm + cx.i)];
-    r.c = bilerp(q0, cx, cy);
-    r.xp = bilerp(q1, cxp, cy);
-    r.xm = bilerp(q2, cxm, cy);
-    r.yp = bilerp(q3, cx, cyp);
-    r.ym = bilerp(q4, cx, cym);
-#endif
-    return r;
+    return sample5_finish(sample5_issue<CLAMP>(L, X, Y));
 }
 
 // ---- software log (src/patch_match.cpp:305 calls std::log(double)) ------------------------------

@@ -61,6 +61,7 @@ struct pagk_ctx {
     // 2-wave MFMA variant from ~2500 features, one wave per feature from ~10000.
     int mfma_min_features = 2500;   // PAGK_MFMA_MIN
     int wave_min_features = 10000;  // PAGK_WAVE_MIN
+    int quad_min_features = 1 << 30;  // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
@@ -307,10 +308,22 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         // MFMA variant: instantiated for the common patch sizes; chosen explicitly (kernel 2) or,
         // by default, when the launch has more features than can be resident at once
         const bool mfma_ok = a.half == 5 || a.half == 7 || a.half == 10;
-        const bool use_wave = mfma_ok && (ctx->kernel == 3 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
+        // four features per wave: no NCC epilogue of its own (calc_ncc launches run the one-wave-per-feature variant)
+        const bool use_quad = mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->quad_min_features));
+        const bool use_wave = !use_quad && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
         const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        } else if (use_quad) {
+            auto launch = [&](auto kern) -> hipError_t {
+                hipLaunchKernelGGL(kern, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e = hipErrorInvalidValue;
+            if (a.half == 5) e = launch(k_track_quad<2>);        // P = 121: 2 chunks of 64 pixels
+            else if (a.half == 7) e = launch(k_track_quad<4>);   // P = 225
+            else if (a.half == 10) e = launch(k_track_quad<7>);  // P = 441
+            HIPCHK(ctx, e);
         } else if (use_wave) {
             // one wavefront per feature (pagk_wave_kernel.h)
             const size_t lds = track_wave_lds_bytes(a.half);
@@ -585,6 +598,7 @@ int pagk_create(pagk_ctx **out, int device)
     ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
+    if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     for (int k = 0; k < 2; k++) {
         if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
             pagk_destroy(ctx);
@@ -627,7 +641,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
 
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
-    if (!ctx || which < 0 || which > 4) return PAGK_E_ARG;
+    if (!ctx || which < 0 || which > 5) return PAGK_E_ARG;
     ctx->kernel = which;
     return PAGK_OK;
 }
@@ -1351,3 +1365,5 @@ int pagk_match_features(int32_t n, int32_t cap, const int32_t *count, const int3
 }
 
 }  // extern "C"
+
+#include "pagk_multi.h"

@@ -600,8 +600,9 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #ifdef PAGK_STAMPS
     // diagnostic build only: cycles per phase, summed over iterations, written to a.dbg (a buffer
     // nothing else reads).  [0] level setup, [1] sampling, [2] chains, [3] solve, [4] update, [5] total
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_begin = __builtin_amdgcn_s_memtime(), t0, t1;
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 #define STAMP(k)                                  \
     t1 = __builtin_amdgcn_s_memtime();            \
     st[k] += t1 - t0;                             \
@@ -662,12 +663,20 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
                                   (by - ext_y >= 0.0f) && (by + ext_y < L2.frows_m1);
             // all rounds' gathers are issued before any is consumed (lanes past the patch sample
             // a valid pixel and simply do not store)
-            Five smp[NR];
+            FiveTaps taps[NR];
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 float X = bx + wx[r], Y = by + wy[r];
-                smp[r] = interior ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
+                taps[r] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
             }
+#ifdef PAGK_STAMPS
+            STAMP(8)   // coordinates computed, gathers issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(9)   // gathers returned
+#endif
+            Five smp[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) smp[r] = sample5_finish(taps[r]);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 int p = tid + kBlock * r;
@@ -694,6 +703,10 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
                     esq[p] = e * e;  // :294
                 }
             }
+#ifdef PAGK_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(10)  // interpolation, products, LDS stores done in this wave
+#endif
             __syncthreads();
             STAMP(1)
             // the dependent chain and the solve are a feature's critical path: while they run, this wave wins
@@ -895,9 +908,11 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #ifdef PAGK_STAMPS
     if (tid == 0 && a.dbg) {
         st[5] = __builtin_amdgcn_s_memtime() - t_begin;
-        for (int k = 0; k < 6; k++) a.dbg[(size_t)i * 8 + k] = st[k];
-        a.dbg[(size_t)i * 8 + 6] = (unsigned long long)iters;
-        a.dbg[(size_t)i * 8 + 7] = t_begin;
+        for (int k = 0; k < 6; k++) a.dbg[(size_t)i * 16 + k] = st[k];
+        a.dbg[(size_t)i * 16 + 6] = (unsigned long long)iters;
+        a.dbg[(size_t)i * 16 + 7] = rt_begin;  // 100 MHz wall clock, common to all XCDs (s_memtime is per XCD)
+        for (int k = 8; k < 11; k++) a.dbg[(size_t)i * 16 + k] = st[k];
+        a.dbg[(size_t)i * 16 + 11] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 #undef STAMP
@@ -929,5 +944,6 @@ __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs
 }  // namespace pagk
 
 #include "pagk_wave_kernel.h"
+#include "pagk_quad_kernel.h"
 #include "pagk_score_kernel.h"
 #include "pagk_neighbor_kernel.h"

@@ -1,0 +1,245 @@
+// pagk_quad_kernel.h -- k_track_quad: the Gauss-Newton loop with FOUR FEATURES PER WAVEFRONT.
+//
+// The throughput form of the path for launches with (many) more features than the chip has SIMDs.  One wave64
+// owns four features, and every part of an iteration that one feature cannot fill a wave with is shared:
+//
+//   H, b     v_mfma_f64_4x4x4f64 has four independent 4x4 blocks: block q accumulates feature q.  With
+//            A = J = (Ix, Iy, c, 1) and B = (Ix, Iy, -e, c) one block yields every entry the solve reads:
+//            D[i][0..1] = H[i][0..1], D[i][2] = sum J_i * (-e) = b_i, D[2][3] = sum c*c = H22, D[3][0..1] =
+//            H30, H31 (H32 = P*c and H33 = P are exact closed forms).  The instruction is a sequential FMA chain
+//            over k = four consecutive patch pixels in ascending order (tools/microbench7.hip), the products are
+//            exact, so this is the reference's `H += J*J^T; b += -J*e` (src/patch_match.cpp:293-296) -- one
+//            instruction per four pixels for FOUR features, operands read from LDS already widened (the widening
+//            is done once per pixel by the sampling lanes, 64 useful lanes per instruction);
+//   cost     the ordered f32 sum of e*e (:294) is a 16-lane DPP row chain: the wave's four rows are the four
+//            features, one instruction stream;
+//   solve    lane = feature: every lane of row q runs feature q's 4x4 LLT / solve / update (:302-344); four
+//            different solves share each f64 divide and sqrt sequence.
+//
+// Sampling is per feature (64 lanes x one pixel each, a "chunk" of 64 patch pixels at a time, skipped for a
+// feature that has left the iteration loop of the level); chunk c of all four features is sampled, then folded
+// into the MFMA and cost chains, so LDS holds one chunk: ~9.5 KB per wave, 16 waves per CU.
+//
+// The four features run the level's iterations in lockstep; a feature that converges early waits for the others
+// of its wave at the level boundary (its block / row keeps accumulating values nobody reads).  Results are
+// bit-identical to the oracle and to the other variants (tests/test_parity_gpu.py).
+#pragma once
+#include "pagk_chain_asm.h"
+#include "pagk_device.h"
+
+namespace pagk {
+
+__device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
+                                              float lastCost, int level0_ran, float ncc, int iters);
+__device__ __forceinline__ uint32_t lds_off(const void *p);
+
+struct QuadLds {
+    double chunk[3][4][66];  // X | Y | NE streams of the current chunk: [stream][feature][pixel]; the strides put the
+                             // three streams 64 B and the four features 16 B apart modulo the 256-B bank span
+    double cconst[4][34];    // 16 x c per feature (A operand of entry 2, B operand of entry 3), 16 B apart mod 256
+    double ones[32];         // 16 x 1.0 (A operand of entry 3)
+    double acc[4][16];       // D of the four blocks after the last chunk
+    float sq[4 * 129 + 64];  // per feature: carry, 64 squares; rows 129 floats apart (odd: rows 0/1 use disjoint banks)
+};
+
+__device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+template <int NCH>
+__global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
+{
+    __shared__ __attribute__((aligned(256))) QuadLds S;
+    const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
+    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd;
+    const int raw = 4 * (int)blockIdx.x + row;
+    const int fi = raw < a.n ? raw : a.n - 1;  // rows past the end shadow the last feature and write nothing
+    const bool live = raw < a.n && a.status_in[fi] != 0;
+
+    const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
+    float p2x = init[2 * fi], p2y = init[2 * fi + 1];
+    float A00 = 1, A01 = 0, A10 = 0, A11 = 1;
+    if (a.use_affine) {
+        A00 = a.affine[4 * fi], A01 = a.affine[4 * fi + 1], A10 = a.affine[4 * fi + 2], A11 = a.affine[4 * fi + 3];
+    }
+    const float refx = a.pt_ref[2 * fi], refy = a.pt_ref[2 * fi + 1];
+    const float fh = (float)h;
+    const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
+    const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
+    if (__ballot(live) == 0ull) {  // nothing to track in this wave (:173)
+        if (lr == 0 && raw < a.n) write_outputs(a, fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
+        return;
+    }
+
+    // lane -> patch pixel of chunk c: p = 64 c + lane, row-major (y outer, :233-234); x and y as two int16
+    int pxy[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        int p = 64 * c + lane;
+        p = p < P ? p : P - 1;
+        const int yy = p / Wd, xx = p - yy * Wd;
+        pxy[c] = ((xx - h) & 0xffff) | ((yy - h) << 16);
+    }
+
+    // MFMA operand roles of this lane (layout measured: A(q,i,k) in lane 16k+4q+i, B(q,k,j) in lane 16k+4q+j,
+    // D(q,i,j) in lane 16i+4q+j): k = pixel within the group of four, q = block = feature, i = entry.
+    //   A = (Ix, Iy, c, 1)[i]   B = (Ix, Iy, -e, c)[i]
+    const int mk = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
+    const double *a_src = mi < 2 ? &S.chunk[mi][mq][mk] : (mi == 2 ? &S.cconst[mq][mk] : &S.ones[mk]);
+    const double *b_src = mi < 3 ? &S.chunk[mi][mq][mk] : &S.cconst[mq][mk];
+    const int a_step = mi < 2 ? 16 : 0, b_step = mi < 3 ? 16 : 0;  // doubles per four groups
+    if (lane < 32) S.ones[lane] = 1.0;
+    const uint32_t sq_addr = lds_off(&S.sq[row * 129]) + 8u * lr;
+
+    int succ = 1, iters = 0;
+    float lastCost = 0.0f;
+
+    for (int level = a.n_levels - 1; level >= 0; level--) {
+        const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
+        const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
+        float nx, ny;
+        if (level == a.n_levels - 1) {  // :180
+            nx = p2x * a.scales[level];
+            ny = p2y * a.scales[level];
+        } else {  // :182
+            nx = (float)((double)(p2x * 1.0f) / 0.5);
+            ny = (float)((double)(p2y * 1.0f) / 0.5);
+        }
+        float dx = nx - ptx, dy = ny - pty, dg = 0.0f, db = 0.0f;  // :186-191
+        lastCost = 0.0f;                                            // :193
+        succ = 1;                                                   // :194
+        bool act = live;
+
+        // img1 samples are iteration-invariant (bit-identical to :253, :263): once per level, for all four features
+        const float cneg = -sample<true>(L1, ptx, pty);
+        const double cd = (double)cneg;
+        float s1[4][NCH];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const float fx = rl(ptx, 16 * f), fy = rl(pty, 16 * f);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const float x = (float)(short)(pxy[c] & 0xffff), y = (float)(pxy[c] >> 16);
+                s1[f][c] = sample<true>(L1, fx + x, fy + y);
+            }
+        }
+        __syncthreads();  // the previous level's readers of cconst are done
+        S.cconst[row][lr] = cd;
+        __syncthreads();
+
+        for (int iter = 0; iter < a.iterations; iter++) {  // :215
+            const unsigned long long actm = __ballot(act);
+            if (actm == 0ull) break;
+            if (act) iters++;
+            const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
+            const float gain = 1.0f + dg;
+            const bool interior = (bx - ext_x >= 0.0f) && (bx + ext_x < L2.fcols_m1) && (by - ext_y >= 0.0f) &&
+                                  (by + ext_y < L2.frows_m1);
+            const unsigned long long intm = __ballot(interior);
+            double d = 0.0;      // the four 4x4 accumulators (:217-218 H = 0, b = 0)
+            float carry = 0.0f;  // cost = 0 (:283)
+
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                // ---- sampling: chunk c of every active feature --------------------------------------
+                const float x = (float)(short)(pxy[c] & 0xffff), y = (float)(pxy[c] >> 16);
+                const bool valid = 64 * c + lane < P;
+                for (int f = 0; f < 4; f++) {
+                    if (!((actm >> (16 * f)) & 1ull)) continue;  // wave-uniform
+                    const int src = 16 * f;
+                    float wx = x, wy = y;
+                    if (a.use_affine) {  // :203-204
+                        wx = rl(A00, src) * x + rl(A01, src) * y;
+                        wy = rl(A10, src) * x + rl(A11, src) * y;
+                    }
+                    const float X = rl(bx, src) + wx, Y = rl(by, src) + wy;
+                    const Five s = ((intm >> src) & 1ull) ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
+                    const float s1v = f == 0 ? s1[0][c] : (f == 1 ? s1[1][c] : (f == 2 ? s1[2][c] : s1[3][c]));
+                    const float e = s.c + rl(db, src) - rl(gain, src) * s1v;  // :252-253
+                    const float Ix = 0.5f * (s.xp - s.xm);                     // :259-260
+                    const float Iy = 0.5f * (s.yp - s.ym);                     // :261-262
+                    S.chunk[0][f][lane] = (double)Ix;
+                    S.chunk[1][f][lane] = (double)Iy;
+                    S.chunk[2][f][lane] = -(double)e;
+                    S.sq[f * 129 + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
+                }
+                if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
+                __syncthreads();
+                // ---- H, b: one MFMA per four pixels, all four features ---------------------------------
+                {
+                    const int left = P - 64 * c;                   // valid pixels from this chunk on
+                    const int ng = left >= 64 ? 16 : (left >> 2);  // complete groups of four
+                    const double *pa = a_src, *pb = b_src;
+                    int m = 0;
+                    for (; m + 4 <= ng; m += 4) {
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            av[u] = pa[4 * u];
+                            bv[u] = pb[4 * u];
+                        }
+                        pa += a_step;
+                        pb += b_step;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
+                    }
+                    for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
+                    if (left < 64 && (left & 3)) {
+                        // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
+                        const int u = ng & 3;
+                        const bool pad = mk >= (left & 3);
+                        const double av = pa[4 * u], bv = pb[4 * u];
+                        d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
+                    }
+                }
+                // ---- cost: ordered f32 sum, row q = feature q ----------------------------------------
+                carry = chain_rows_f32<1>(sq_addr, 128u, 2);
+                __syncthreads();  // the chunk has been read before the next one is written
+            }
+            // ---- solve (:302-319): D(q, i, j) sits in lane 16 i + 4 q + j; every lane of row q solves feature q
+            S.acc[mq][mk * 4 + mi] = d;
+            __syncthreads();
+            double H[4][4], b[4], upd[4];
+            {
+                const double *A = S.acc[row];
+                H[0][0] = A[0], H[1][0] = A[4], H[1][1] = A[5];
+                H[2][0] = A[8], H[2][1] = A[9], H[2][2] = A[11];
+                H[3][0] = A[12], H[3][1] = A[13];
+                H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
+                H[3][3] = (double)P;       // sum of 1.0*1.0
+                b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
+            }
+            float cost = carry;
+            if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+            const double unorm = llt4_solve_norm(H, b, upd);
+            __syncthreads();  // S.acc is rewritten by the next iteration
+            // ---- update + termination (:322-344), per feature ------------------------------------------
+            if (act) {
+                if (upd[0] != upd[0]) {  // :322
+                    succ = 0;
+                    act = false;
+                } else if (iter > 0 && cost > lastCost) {  // :328
+                    act = false;
+                } else {
+                    dx = (float)((double)dx + upd[0]);  // :332
+                    dy = (float)((double)dy + upd[1]);
+                    if (a.illum) {  // :334-337
+                        dg = (float)((double)dg + upd[2]);
+                        db = (float)((double)db + upd[3]);
+                    }
+                    lastCost = cost;  // :339
+                    succ = 1;
+                    if (unorm < 1e-2) act = false;  // :343
+                }
+            }
+        }
+        p2x = ptx + dx;  // :348
+        p2y = pty + dy;
+    }
+    if (lr == 0 && raw < a.n) {
+        if (live)
+            write_outputs(a, fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)
+        else
+            write_outputs(a, fi, init[2 * fi], init[2 * fi + 1], 0, 0.0f, 0, 0.0f, 0);
+    }
+}
+
+}  // namespace pagk

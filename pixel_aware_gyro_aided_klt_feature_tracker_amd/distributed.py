@@ -23,24 +23,26 @@ FORCE_COLLECTIVE = False  # tests: run the all-gather even with one rank
 BYTES_PER_FEATURE = sum(torch.empty(0, dtype=dt).element_size() * k for _, dt, k in FIELDS)  # 41
 
 
+COMM = None  # a capi.Multi: when set, the all-gather goes through the library's own RCCL communicator (C ABI)
+
+
 def shard_size(n: int, world: int) -> int:
     return (n + world - 1) // world
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
-    m = shard_size(n, world)
-    lo = min(n, rank * m)
-    return lo, min(n, lo + m)
+    """The partition is defined once, behind the C ABI (pagk_shard_range)."""
+    from . import capi
+    return capi.shard_range(n, rank, world)
 
 
 def alloc_device_outputs(m: int, device) -> dict:
     """Per-rank output arrays for pagk_track_device, carved out of ONE byte buffer so that
     the all-gather ships a single contiguous slice.  SoA blocks, each 8-byte aligned."""
+    from . import capi
     m = max(m, 1)
-    offs, total = {}, 0
-    for name, dt, k in FIELDS:
-        offs[name] = total
-        total += (torch.empty(0, dtype=dt).element_size() * k * m + 7) // 8 * 8
+    o, total = capi.shard_layout(m)   # the slice layout is the library's (pagk_shard_layout)
+    offs = {name: o[i] for i, (name, _, _) in enumerate(FIELDS)}
     buf = torch.zeros(total, dtype=torch.uint8, device=device)
     out = {"_buf": buf, "_m": m}
     for name, dt, k in FIELDS:
@@ -84,14 +86,19 @@ class Gathered:
 def all_gather_results(local: dict, n: int, group=None, out: torch.Tensor | None = None):
     """One all-gather of every rank's packed slice (RCCL `ncclAllGather` of bytes under backend
     "nccl").  Returns the local views when there is a single rank, else a Gathered."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = COMM.world if COMM is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
     m = local["_m"]
-    if world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVE):
+    if world == 1 and not ((dist.is_initialized() or COMM is not None) and FORCE_COLLECTIVE):
         return {name: local[name][:n] for name, _, _ in FIELDS}
     buf = local["_buf"]
     if out is None or out.numel() != world * buf.numel():
         out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if COMM is not None:
+        # the library's communicator: ncclAllGather issued by libpagk_hip.so on torch's current stream (the
+        # tracker's), i.e. ordered after the tracking launch that filled `buf`
+        COMM.allgather([buf], [out], buf.numel(), streams=[torch.cuda.current_stream(buf.device).cuda_stream])
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
     return Gathered(out, world, m, n, buf.numel())
 
 

@@ -43,12 +43,14 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [37, 64, 1])
-def test_sharded_gather_equals_single_process(built, n):
+@pytest.mark.parametrize("n,world", [(37, 2), (64, 2), (1, 2), (7, 3), (4, 3)])
+def test_sharded_gather_equals_single_process(built, n, world):
+    # (7, 3): ragged last shard; (4, 3): ceil(4/3) = 2 -> shards of 2, 2 and an EMPTY trailing shard; (1, 2): one
+    # rank has nothing to track
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + n) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 17 * n + world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
@@ -57,11 +59,44 @@ def test_sharded_gather_equals_single_process(built, n):
     assert q.get(timeout=5) is True
 
 
-def test_shard_ranges_cover_in_order():
+def test_shard_ranges_cover_in_order(built):
     from pixel_aware_gyro_aided_klt_feature_tracker_amd import distributed
-    for n in (0, 1, 7, 8, 9, 20000):
-        for world in (1, 2, 4, 8):
+    for n in (0, 1, 4, 7, 8, 9, 20000):
+        for world in (1, 2, 3, 4, 8):
             spans = [distributed.shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(hi - lo <= distributed.shard_size(n, world) for lo, hi in spans)
+
+
+def test_partition_and_slice_layout_behind_the_c_abi(built):
+    """pagk_shard_range / pagk_shard_layout (include/pagk.h) against their definitions: contiguous blocks of
+    ceil(n / G); seven SoA blocks in SetMatcher order, each padded to 8 bytes."""
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed
+    for n in (0, 1, 4, 5, 37, 1000, 20000):
+        for world in (1, 2, 3, 8):
+            m = -(-n // world)
+            for r in range(world):
+                lo, hi = capi.shard_range(n, r, world)
+                assert (lo, hi) == (min(n, r * m), min(n, r * m + m))
+    elem = [8, 8, 1, 8, 8, 4, 4]
+    for m in (0, 1, 3, 8, 125, 2500):
+        offs, total = capi.shard_layout(m)
+        want, t = [], 0
+        for e in elem:
+            want.append(t)
+            t += (e * max(m, 1) + 7) // 8 * 8
+        assert offs == want and total == t
+        out = distributed.alloc_device_outputs(m, "cpu")     # the Python runtime carves its views from the same layout
+        assert out["_buf"].numel() == total
+        assert sum(torch.empty(0, dtype=dt).element_size() * k for _, dt, k in distributed.FIELDS) == sum(elem)
+
+
+def test_group_creation_fails_loudly_without_a_device(built):
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("needs a machine without a HIP device")
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi
+    with pytest.raises(capi.PagkError) as e:
+        capi.Multi([0])
+    assert e.value.code == capi.PAGK_E_NODEVICE

@@ -86,6 +86,27 @@ def test_wave_kernel_on_baseline_configs(ctx, idx, n):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_quad_kernel_matches_golden_vectors(ctx, name):
+    # four features per wave: block q of the f64 MFMA, row q of the cost chain, lane = feature solve
+    params, inp, exp = load_golden(name)
+    ctx.set_kernel(5)
+    try:
+        got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                        inp["status_in"])
+    finally:
+        ctx.set_kernel(0)
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("idx,n", [(1, 1000), (1, 1001), (1, 1002), (1, 1003), (3, 6000)])
+def test_quad_kernel_on_baseline_configs(ctx, idx, n):
+    # n not a multiple of four: the last wave's spare rows shadow the last feature and write nothing
+    w = synth.config(idx, n=n)
+    got, ref = run_both(ctx, params_for(w), w, kernel=5)
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+
+
 @pytest.mark.parametrize("idx,n", [(0, 500), (1, 1000), (2, 2000), (3, 3000)])
 def test_baseline_configs_against_oracle(ctx, idx, n):
     # BASELINE.json configs (synthetic stand-ins); 21x21 patch, 30 iterations
@@ -184,7 +205,7 @@ def test_garbage_coordinates_are_safe_and_defined(ctx):
     p = params_for(w)
     with np.errstate(all="ignore"):
         ref = orc.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
-    for k in (0, 1, 2, 3):
+    for k in (0, 1, 2, 3, 5):
         ctx.set_kernel(k)
         try:
             got = ctx.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
@@ -486,7 +507,7 @@ def test_randomized_parity_sweep(ctx, seed):
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                          camera=w.camera, **flags)
     ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
-    for kernel in (0, 1, 2, 3):   # auto, thread-per-feature, MFMA 2-wave, wave-per-feature (fall back where not built)
+    for kernel in (0, 1, 2, 3, 5):   # auto, thread-per-feature, MFMA 2-wave, wave-per-feature, four features per wave (fall back where not built)
         ctx.set_kernel(kernel)
         try:
             got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
