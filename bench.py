@@ -2,38 +2,38 @@
 """bench.py -- tracked features / second of the pyramidal patch-based KLT refinement
 (21x21 patch, 3 levels, <= 30 Gauss-Newton iterations) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: spawns its N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is what a tracker does per new frame: build the pyramid of the current frame
 (CreatePyramids) and run PatchMatch over the frame's keypoints, everything already resident in
 HBM.  Workload at N=1: BASELINE.json configs[1] (752x480, 1000 keypoints, gyro-predicted affine
-init; synthetic stand-in).  For N>1 the same frame pair carries N x 1000
-keypoints, sharded in contiguous index blocks, one process per GPU, and every step ends with the
-RCCL all-gather of the per-rank (pt, status, err) slices: weak scaling.  Rank 0 prints ONE JSON
-line.
+init; synthetic stand-in).  For N>1, `--scaling weak` (default) tracks
+N x 1000 keypoints on the same pair and `--scaling strong --config 3` the 1080p / 20000-keypoint
+pair of configs[3]; either way the keypoints are sharded in contiguous index blocks, one process
+per GPU, and every step ends with the RCCL all-gather of the per-rank (pt, status, err) slices.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NOMINAL_N = {0: 500, 1: 1000, 2: 2000, 3: 20000, 4: 4000}   # keypoints BASELINE.json quotes per config
 
 
 def algorithmic_bytes_per_feature(h: int, L: int) -> int:
-    """SURVEY.md §8(d): L*[(2h+2)^2 + (2h+4)^2] window bytes + 33 B in + 37 B out."""
+    """SURVEY.md section 8(d): L*[(2h+2)^2 + (2h+4)^2] window bytes + 33 B in + 37 B out."""
     return L * ((2 * h + 2) ** 2 + (2 * h + 4) ** 2) + 70
 
 
@@ -50,22 +50,127 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("PAGK_CPU_THREADS", "16"))))
 
 
-def measured_traffic(workload_name: str, n: int, kernel: str = "k_track_block"):
-    """HBM bytes per launch of `kernel` from the committed PMC profile of this workload
-    (profiles/<tag>/pmc_summary.json; collected by tools/profile.sh in separate --pmc passes)."""
+def measured_traffic(workload_name: str, n: int, kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC profile of THIS workload
+    (profiles/<tag>/pmc_summary.json next to the bench.json it was collected with; tools/profile.sh,
+    separate --pmc passes)."""
     try:
         pdir = os.path.join(ROOT, "profiles")
-        tag = sorted(d for d in os.listdir(pdir) if os.path.isdir(os.path.join(pdir, d)))[-1]
-        with open(os.path.join(pdir, tag, "pmc_summary.json")) as f:
-            prof = json.load(f)
-        with open(os.path.join(pdir, tag, "bench.json")) as f:
-            ref = json.load(f)
-        if ref["config"]["workload"].split(":")[0] != workload_name or ref["config"]["features_total"] != n:
-            return None, None
-        k = next(v for name, v in prof.items() if f"::{kernel}<" in name)
-        return (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0, tag
+        for tag in sorted((d for d in os.listdir(pdir) if os.path.isdir(os.path.join(pdir, d))), reverse=True):
+            try:
+                with open(os.path.join(pdir, tag, "pmc_summary.json")) as f:
+                    prof = json.load(f)
+                with open(os.path.join(pdir, tag, "bench.json")) as f:
+                    ref = json.load(f)
+            except Exception:
+                continue
+            if ref["config"]["workload"].split(":")[0] != workload_name or ref["config"]["features_total"] != n:
+                continue
+            for name, v in prof.items():
+                if f"::{kernel}<" in name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    return (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0, tag
     except Exception:
-        return None, None
+        pass
+    return None, None
+
+
+KERNEL_OF_VARIANT = {0: "k_track_block", 1: "k_track_thread", 2: "k_track_block", 3: "k_track_wave", 4: "k_track_block",
+                     5: "k_track_quad"}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never
+    touches the GPU), one per GPU, rendezvous on 127.0.0.1.  Rank 0's stdout is ours."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def time_steps(rt, steps: int, warmup: int, mode: str, barrier=None):
+    import torch
+    for _ in range(warmup):
+        out = rt.step(mode=mode)
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = rt.step(mode=mode)
+    rt.finish()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def kernel_time_ms(rt, reps: int) -> tuple[float, float]:
+    """Average duration of the tracking launch and of the pyramid launch: HIP events recorded by the library on
+    the stream the kernels run on (pagk_last_kernel_ms); untimed extra launches, outside any graph."""
+    import numpy as np
+    import torch
+    trk, pyr = [], []
+    torch.cuda.synchronize()
+    with torch.cuda.stream(rt.main):
+        for _ in range(reps):
+            rt.rebuild_current_pyramid(1)
+            rt.track_shard(1)
+            a, b = rt.ctx.last_kernel_ms()
+            trk.append(a)
+            pyr.append(b)
+    return float(np.mean(trk)), float(np.mean(pyr))
+
+
+def config_row(cfg_idx: int, n: int, device: int, steps: int, streams: int = 1) -> dict:
+    """One BASELINE config on this GPU: `streams` independent resident trackers of that shape stepped in graph
+    mode, plus the tracking kernel's own time and roofline figures."""
+    import numpy as np
+    import torch
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
+    w = synth.config(cfg_idx, n=n)
+    p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
+                         camera=w.camera)
+    cams = []
+    for _ in range(streams):
+        rt = runtime.ResidentTracker(p, device=device)
+        rt.load_pair(w.img_ref, w.img_cur)
+        rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+        cams.append(rt)
+    for _ in range(3):
+        for rt in cams:
+            out = rt.step(mode="graph")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for rt in cams:
+            out = rt.step(mode="graph")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kms, pms = kernel_time_ms(cams[0], 10)
+    res = distributed.to_numpy(out)
+    it = res["iters"][:w.n]
+    b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
+    row = {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]}, {w.n} keypoints ({w.n_active} active), "
+                       f"h={w.half_patch}, L={w.pyramids}, I={w.iterations}" + (f", {streams} concurrent streams" if streams > 1 else ""),
+           "ms_per_step": dt * 1e3, "features_per_s": w.n_active * streams / dt,
+           "mean_iters": float(it[w.status_in > 0].mean()), "max_iters": int(it.max()),
+           "variant": capi.Context.VARIANT_NAMES.get(cams[0].ctx.last_variant(), "?"),
+           "kernel_ms": kms, "pyramid_ms": pms,
+           "roofline_frac": w.n_active * b_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    for rt in cams:
+        rt.close()
+    return row
 
 
 def main() -> int:
@@ -73,38 +178,68 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--features-per-gpu", type=int, default=1000)
+    ap.add_argument("--features-per-gpu", type=int, default=None, help="weak scaling: keypoints per GPU (default: the config's own count)")
     ap.add_argument("--config", type=int, default=1, help="synth.config index (1 = BASELINE configs[1])")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: N x the config's keypoints; strong: the config's keypoints split over N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the host-path and multi-camera side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-config table and the side measurements")
     ap.add_argument("--cameras", type=int, default=4, help="independent streams of the multi-camera side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the CPU baseline sample")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)   # before anything touches the GPU in this process
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; the HIP path is the product and has no CPU fallback",
               file=sys.stderr)
         return 3
     torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("PAGK_FORCE_DIST") == "1" and "RANK" in os.environ  # exercise RCCL with 1 rank
+    force_dist = os.environ.get("PAGK_FORCE_DIST") == "1"  # exercise the collective with 1 rank
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
+
+    # The data path's collective belongs to the library (pagk_multi_*: ncclAllGather issued by libpagk_hip.so).
+    # torch.distributed only carries the 128-byte RCCL id, the barriers and the max-over-ranks of the timing; with
+    # PAGK_GATHER=torch (or if the library's communicator cannot be formed) the gather itself falls back to
+    # torch.distributed's RCCL backend -- still RCCL, still on the tracker's stream -- and the JSON line says so.
+    gather_via = "none"
+    comm = None
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        want_capi = os.environ.get("PAGK_GATHER", "capi") == "capi"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        gather_via = "torch.distributed (RCCL backend)"
+        if want_capi:
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(capi.Multi.unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                comm = capi.Multi(uid=bytes(uid.cpu().numpy().tobytes()), rank=rank, world=world, device=local_rank)
+                distributed.COMM = comm
+                gather_via = "pagk_multi_allgather (libpagk_hip.so -> ncclAllGather)"
+            except Exception as e:   # noqa: BLE001 -- any failure here must not lose the run
+                print(f"bench.py: library communicator unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
+                comm = None
     distributed.FORCE_COLLECTIVE = force_dist
 
-    # identical inputs on every rank (seeded generator), n_total = world x features_per_gpu
-    n_total = args.features_per_gpu * world
+    # identical inputs on every rank (seeded generator)
+    per_gpu = args.features_per_gpu or NOMINAL_N[args.config]
+    n_total = NOMINAL_N[args.config] if args.scaling == "strong" else per_gpu * world
     w = synth.config(args.config, n=n_total)
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids,
                          has_gyro=w.has_gyro, camera=w.camera)
@@ -114,54 +249,42 @@ def main() -> int:
     n_active_total = w.n_active
     n_active_local = int(np.count_nonzero(w.status_in[rt.lo:rt.hi]))
 
-    # how a step's launches reach the GPU (runtime.ResidentTracker.step): "fused" = PatchMatch of the pair and the
-    # pyramid of the following frame in ONE launch, replayed as a single-node hipGraph; "graph" = pyramid then
-    # PatchMatch as a two-node graph (valid for a live camera with no frame of look-ahead)
-    step_mode = os.environ.get("PAGK_STEP_MODE", "fused")
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        out = rt.step(mode=step_mode)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = rt.step(mode=step_mode)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # `value`: the step a live camera loop can use -- "graph": pyramid(current frame) -> PatchMatch replayed as one
+    # hipGraph (multi-GPU: the two launches, then the all-gather on a side stream, see runtime.ResidentTracker.step).
+    # PAGK_STEP_MODE=fused times the look-ahead form instead (needs frame k+1 while pair (k-1, k) is tracked).
+    step_mode = os.environ.get("PAGK_STEP_MODE", "graph")
+    elapsed, out = time_steps(rt, args.steps, args.warmup, step_mode, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    mode_used = rt.mode_used
 
-    # dominant kernel (k_track_block): average launch duration, HIP events recorded by the
-    # library on the stream the kernel runs on (pagk_last_kernel_ms); untimed extra launches.
-    trk, pyr = [], []
-    torch.cuda.synchronize()
-    fused_kernel = rt.mode_used == "fused"
-    with torch.cuda.stream(rt.main):
-        for k in range(min(50, max(10, args.steps))):
-            if fused_kernel:   # the launch of the timed loop: k_track_block_pyr (tracking + next frame's pyramid)
-                rt.track_shard_fused(1 + (k & 1))
-            else:
-                rt.rebuild_current_pyramid(1)
-                rt.track_shard(1)
-            a, b = rt.ctx.last_kernel_ms()
-            trk.append(a)
-            pyr.append(b)
-    kernel_ms = float(np.mean(trk))
-    pyramid_ms = None if fused_kernel else float(np.mean(pyr))
-
+    kernel_ms, pyramid_ms = kernel_time_ms(rt, min(50, max(10, args.steps)))
+    variant = rt.ctx.last_variant()
     res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
     extras = {}
+    if world > 1 or force_dist:
+        # the collective by itself (events on the stream it runs on), and the same steps without it
+        extras["gather"] = rt.gather_report(min(50, max(10, args.steps)))
+        extras["gather"]["via"] = gather_via
+        t_nog, _ = time_steps(rt, max(10, args.steps // 4), 3, step_mode + "-nogather", barrier)
+        extras["gather"]["ms_per_step_without_gather"] = t_nog / max(10, args.steps // 4) * 1e3
     if rank == 0 and world == 1 and not args.no_extras:
+        # the look-ahead step beside the headline, and how the two launches can reach the GPU
+        ksteps = max(20, args.steps // 2)
+        modes = {}
+        for m in ("graph", "fused", "serial", "streams"):
+            t1, _ = time_steps(rt, ksteps, 5, m)
+            modes[m] = t1 / ksteps * 1e3
+        extras["step_modes_ms"] = modes
+        extras["step_modes_note"] = ("graph = value's mode (valid for a live camera); fused = PatchMatch + the NEXT frame's pyramid "
+                                     "in one launch (needs one frame of look-ahead)")
         # (a) the drop-in call itself: pagk_track on HOST buffers -- two frame uploads, pyramids, per-feature
         #     arrays in, results out, synchronous.  PCIe-inclusive; never `value`.
         hctx = capi.Context(local_rank)
@@ -176,88 +299,64 @@ def main() -> int:
         extras["host_buffer_path"] = {"value": n_active_total / th, "unit": "features/s", "ms_per_call": th * 1e3,
                                       "what": "pagk_track(): both frames + feature arrays over PCIe, pyramids of both "
                                               "frames, tracking, results back; synchronous"}
-        # (b) multi-camera: C independent frame streams in flight on one GPU (BASELINE configs[4] shape).
-        #     Steps of DIFFERENT cameras do not depend on each other, so their launches overlap and fill the
-        #     tail of each other's slowest features.  Reported beside `value`, not as `value`.
-        C = max(1, args.cameras)
-        cams = []
-        for c in range(C):   # every tracker owns its pair of HIP streams
-            r2 = runtime.ResidentTracker(p, device=local_rank)
-            r2.load_pair(w.img_ref, w.img_cur)
-            r2.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
-            cams.append(r2)
-        def cam_steps(k, **kw):
-            for _ in range(k):
-                for r2 in cams:
-                    r2.step(**kw)
-        cam_steps(5, mode=step_mode)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ksteps = max(20, args.steps // 2)
-        cam_steps(ksteps, mode=step_mode)
-        torch.cuda.synchronize()
-        tc = time.perf_counter() - t1
-        extras["multi_camera"] = {"value": n_active_total * C * ksteps / tc, "unit": "features/s", "cameras": C,
-                                  "steps_per_camera": ksteps,
-                                  "what": f"{C} independent cameras (one hipGraph replay per camera and frame, mode {step_mode}) in "
-                                          "flight on one GPU"}
-        # (c) how the step's two launches reach the GPU (runtime.ResidentTracker.step modes), one camera:
-        #     `value` uses "graph" (one hipGraphLaunch replaying [pyramid -> PatchMatch])
-        modes = {}
-        for m in ("fused", "graph", "serial", "streams"):
-            for _ in range(5):
-                cams[0].step(mode=m)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(ksteps):
-                cams[0].step(mode=m)
-            torch.cuda.synchronize()
-            modes[m] = (time.perf_counter() - t1) / ksteps * 1e3
-        extras["step_modes_ms"] = modes
-        for r2 in cams:
-            r2.close()
+        # (b) every BASELINE config at its own size on this one GPU (configs[3] is the 8-GPU config run unsharded,
+        #     configs[4] one stream and eight concurrent streams of its shape)
+        table = {}
+        ksteps = max(10, min(40, args.steps // 5))
+        for key, (ci, nn, st) in {"configs[1]": (1, 1000, 1), "configs[2]": (2, 2000, 1), "configs[3] on 1 GPU": (3, 20000, 1),
+                                  "configs[4] one stream": (4, 4000, 1), "configs[4] 8 streams on 1 GPU": (4, 4000, 8)}.items():
+            table[key] = config_row(ci, nn, local_rank, ksteps, streams=st)
+        extras["configs"] = table
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
         achieved = n_active_local * b_alg / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_tag = (measured_traffic(w.name, n_total, "k_track_block_pyr" if fused_kernel else "k_track_block")
-                                if world == 1 else (None, None))
+        kname = KERNEL_OF_VARIANT.get(variant, "k_track_block")
+        traffic, traffic_tag = measured_traffic(w.name, n_total, kname) if world == 1 else (None, None)
+        P = (2 * w.half_patch + 1) ** 2
+        it = res["iters"][:n_total]
+        max_it = int(it.max())
         line = {
             "metric": "tracked features/sec (21x21, 3-lvl, 30 iter)",
             "value": n_active_total * args.steps / elapsed,
             "unit": "features/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 sampling, f64 normal equations", "data": "synthetic",
             "config": {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} pair, "
-                                   f"{args.features_per_gpu} keypoints/GPU, gyro-predicted affine init, "
-                                   f"h={w.half_patch}, L={w.pyramids}, I={w.iterations} "
-                                   "(synthetic stand-in for BASELINE configs[1])",
+                                   f"{n_total} keypoints ({n_total // world if args.scaling == 'strong' else per_gpu}/GPU), "
+                                   f"gyro-predicted affine init, h={w.half_patch}, L={w.pyramids}, I={w.iterations} "
+                                   f"(synthetic stand-in for BASELINE configs[{args.config}])",
                        "features_total": n_total, "features_active": n_active_total,
-                       "sharding": f"contiguous feature blocks x{world} + all-gather" if world > 1 else "none",
+                       "sharding": f"contiguous feature blocks x{world} + all-gather ({gather_via})" if world > 1 else "none",
                        "step": {"fused": "PatchMatch(all features of the pair) + pyramid(next frame) in ONE launch (trailing "
-                                         "workgroups), replayed as a single-node hipGraph",
-                                "graph": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch"
-                                }.get(rt.mode_used, f"pyramid + PatchMatch issued as direct launches ({rt.mode_used})")
-                               + (" + all-gather" if world > 1 else ""),
-                       "step_mode": rt.mode_used},
+                                         "workgroups), replayed as a single-node hipGraph; needs one frame of look-ahead",
+                                "graph": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch; "
+                                         "valid for a live camera"
+                                }.get(mode_used, f"pyramid + PatchMatch issued as direct launches ({mode_used})")
+                               + (" + all-gather of step k on a side stream, awaited before step k+1's tracking" if world > 1 else ""),
+                       "step_mode": mode_used},
+            # `bound` names the roofline the contract asks to price against; what actually binds the kernel is in
+            # `binding_resource` (the fraction of HBM peak is tiny by construction: ~3.2 KB of compulsory bytes per
+            # feature against ~10 iterations of 441-step ORDERED f64 accumulation)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": (f"profiles/{traffic_tag}/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB "
                                             "per launch") if traffic else None,
-                         "kernel": "k_track_block_pyr" if fused_kernel else "k_track_block", "kernel_ms": kernel_ms,
+                         "kernel": kname, "variant": capi.Context.VARIANT_NAMES.get(variant, "?"), "kernel_ms": kernel_ms,
                          "pyramid_ms": pyramid_ms,
                          "algorithmic_bytes_per_feature": b_alg, "features_per_launch": n_active_local,
-                         "note": "compulsory HBM bytes are ~3.2 KB/feature: the kernel is bound by the ordered f64 "
-                                 "accumulation chain (dependent-FMA latency), not by HBM; see DESIGN.md"
-                                 + ("; the fused launch also builds the next frame's pyramid (6.56 B/pixel, not counted in "
-                                    "`achieved`, included in `traffic`)" if fused_kernel else "")},
+                         "binding_resource": "latency of the reference-ordered accumulation: the launch lasts as long as its "
+                                             "slowest feature (max iterations x [sampling + 441 dependent f64 FMA steps + "
+                                             "4x4 LLT solve]); not HBM",
+                         "ordered_chain_floor_ms": max_it * P * 5.9 / 2.4e9 * 1e3,
+                         "ordered_chain_floor_note": f"{max_it} iterations of the slowest feature x {P} dependent FMA steps x "
+                                                     "5.9 cycles (measured DPP chain step) at 2.4 GHz: what the ordered sums "
+                                                     "alone cost on its critical path"},
         }
-        # iterations executed (the rate is meaningless without it) and parity, rank 0 shard
-        it = res["iters"][:n_total]
         line["mean_iters_per_feature"] = float(it[w.status_in > 0].mean())
-        line["max_iters_per_feature"] = int(it.max())
+        line["max_iters_per_feature"] = max_it
         line.update(extras)
 
         if not args.no_cpu_baseline and world == 1:
@@ -293,6 +392,9 @@ def main() -> int:
         print(json.dumps(line), flush=True)
 
     rt.close()
+    if comm is not None:
+        distributed.COMM = None
+        comm.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -64,7 +64,9 @@ typedef struct pagk_params {
     uint8_t consider_affine;          /* bConsiderAffineDeformation_                      */
     uint8_t regularization_penalty;   /* bRegularizationPenalty_                          */
     uint8_t calculate_ncc;            /* bCalculateNCC_                                   */
-    uint8_t reserved0[2];
+    uint8_t predict_method;           /* pagk_gyro_predict_device only: 0 or 1 = PIXEL_AWARE_PREDICTION, 2 =
+                                         SINGLE_HOMOGRAPHY (ePredictMethod, include/gyro_aided_tracker.h:66-69)   */
+    uint8_t reserved0[1];
     float lambda;            /* mLambda      = 1.0f  (:48) */
     float alpha;             /* mAlpha       = 0.5f  (:49) */
     int32_t max_distance;    /* mMaxDistance = 25    (:50) */
@@ -131,7 +133,8 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels,
 /* ---- the hot path, device-resident (streams of frame pairs, benchmarks) ---- */
 /* Upload a frame into one of the context's frame slots and build its pyramid on
  * the device (CreatePyramids :61-76). In a sequence, cur of pair t is ref of pair
- * t+1, so each frame is uploaded once. slot in [0, 4). */
+ * t+1, so each frame is uploaded once. slot in [0, 4).  Returns after img->data has been read (the caller may
+ * reuse the buffer at once, also when it is pinned memory); the pyramid kernels may still be running. */
 int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids);
 /* Same for an image that already lives in device memory (d_data: device pointer,
  * rows of `step` bytes). Asynchronous on the context stream. */
@@ -176,14 +179,18 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  * 5 = four features per wavefront (block q of the f64 MFMA, row q of the cost chain and lane = feature solve shared
  *     by four features): the highest-throughput variant for very large launches; bit-identical like 0-3. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
+/* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
+ * -1 before the first launch. */
+int pagk_last_variant(const pagk_ctx *ctx);
 
 /* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,
  * measured with HIP events on the stream the kernels ran on. Synchronises. */
 int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms);
 
 /* ---- producer / consumer rows next to the path ----------------------------- */
-/* GyroAidedTracker::GyroPredictFeatures + GyroPredictOnePixel, PIXEL_AWARE_PREDICTION
- * (src/gyro_aided_tracker.cpp:118-185,194-231), on the device: predicted point (un-distorted and
+/* GyroAidedTracker::GyroPredictFeatures + GyroPredictOnePixel (src/gyro_aided_tracker.cpp:118-185,194-256), both
+ * prediction methods (params->predict_method: PIXEL_AWARE_PREDICTION :212-231, or SINGLE_HOMOGRAPHY :233-253, the
+ * same with lambda = 1), on the device: predicted point (un-distorted and
  * distorted), border status and the 2x2 affine A = C B^T (B B^T)^-1 from the four predicted patch corners.
  * Produces exactly the arrays pagk_track_device consumes, so prediction -> tracking needs no host
  * round trip.  All pointers are device pointers; camera model from params (fx fy cx cy dist_coef);

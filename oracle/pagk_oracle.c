@@ -74,6 +74,20 @@ float pagk_oracle_inv_log_max_dist(float alpha, int32_t max_distance)
  * past the buffer.  The reference reads heap garbage there; oracle and product define
  * every byte at offset >= rows*step as 0.
  * ---------------------------------------------------------------------------------------------- */
+/* tools/parity_risk.py: the choices this restatement had to make about third-party arithmetic, switchable one at
+ * a time so that their effect on the results can be measured (oracle/README.md, "How much each guess matters").
+ * 0 = the restatement as documented.  Never set by tests or by the benchmark. */
+static uint32_t g_alt = 0;
+enum {
+    ALT_LOWER_SEQ = 1,   /* lower solve, row 3: (c0 + c1) + c2 instead of c0 + (c1 + c2)           */
+    ALT_UPPER_TREE = 2,  /* upper solve, row 0: c0 + (c1 + c2) instead of (c0 + c1) + c2           */
+    ALT_NORM_SEQ = 4,    /* norm: ((x0^2 + x1^2) + x2^2) + x3^2 instead of the SSE2 packet shape   */
+    ALT_LLT_RECIP = 8,   /* Eigen <= 3.2: A21 *= 1/x instead of A21 /= x                           */
+    ALT_PYR_LINEAR = 16, /* exact 2x decimation through the 11-bit fixed-point bilinear path       */
+    ALT_PIVOT_TREE = 32  /* 4th pivot: A33 - (a0^2 + (a1^2 + a2^2)) instead of the sequential sum  */
+};
+void pagk_oracle_set_alternatives(uint32_t flags) { g_alt = flags; }
+
 typedef struct {
     const uint8_t *data;
     int cols, rows;
@@ -123,7 +137,7 @@ int pagk_oracle_pyr_down(const uint8_t *src, int32_t w, int32_t h, int64_t step,
     if (!src || !dst || w < 2 || h < 2 || step < w) return PAGK_E_ARG;
     /* :69  cv::Size(cols * 0.5, rows * 0.5): int * double, truncated */
     const int dw = (int)(w * 0.5), dh = (int)(h * 0.5);
-    if (!((w & 1) || (h & 1))) { /* scale exactly 2 in x and y: INTER_AREA fast path */
+    if (!((w & 1) || (h & 1)) && !(g_alt & 16 /* ALT_PYR_LINEAR */)) { /* scale exactly 2 in x and y: INTER_AREA fast path */
         for (int y = 0; y < dh; y++) {
             const uint8_t *r0 = src + (int64_t)(2 * y) * step, *r1 = r0 + step;
             for (int x = 0; x < dw; x++)
@@ -201,18 +215,25 @@ static void llt4_inplace(double M[4][4])
         double x = M[k][k];
         if (k > 0) {
             double s = M[k][0] * M[k][0];
-            for (int j = 1; j < k; j++) s += M[k][j] * M[k][j];
+            if (k == 3 && (g_alt & ALT_PIVOT_TREE))
+                s += M[k][1] * M[k][1] + M[k][2] * M[k][2];
+            else
+                for (int j = 1; j < k; j++) s += M[k][j] * M[k][j];
             x -= s;
         }
         if (x <= 0.0) return;
         M[k][k] = x = sqrt(x);
+        const double rx = 1.0 / x;
         for (int i = k + 1; i < 4; i++) {
             if (k > 0) {
                 double s = M[i][0] * M[k][0];
                 for (int j = 1; j < k; j++) s += M[i][j] * M[k][j];
                 M[i][k] -= s;
             }
-            M[i][k] /= x;
+            if (g_alt & ALT_LLT_RECIP)
+                M[i][k] *= rx;
+            else
+                M[i][k] /= x;
         }
     }
 }
@@ -227,7 +248,10 @@ static double llt4_solve_norm(double M[4][4], const double b[4], double x[4])
     r1 /= M[1][1];
     r2 -= M[2][0] * r0 + M[2][1] * r1;
     r2 /= M[2][2];
-    r3 -= M[3][0] * r0 + (M[3][1] * r1 + M[3][2] * r2);
+    if (g_alt & ALT_LOWER_SEQ)
+        r3 -= (M[3][0] * r0 + M[3][1] * r1) + M[3][2] * r2;
+    else
+        r3 -= M[3][0] * r0 + (M[3][1] * r1 + M[3][2] * r2);
     r3 /= M[3][3];
     /* L^T x = y */
     r3 /= M[3][3];
@@ -235,12 +259,16 @@ static double llt4_solve_norm(double M[4][4], const double b[4], double x[4])
     r2 /= M[2][2];
     r1 -= M[2][1] * r2 + M[3][1] * r3;
     r1 /= M[1][1];
-    r0 -= (M[1][0] * r1 + M[2][0] * r2) + M[3][0] * r3;
+    if (g_alt & ALT_UPPER_TREE)
+        r0 -= M[1][0] * r1 + (M[2][0] * r2 + M[3][0] * r3);
+    else
+        r0 -= (M[1][0] * r1 + M[2][0] * r2) + M[3][0] * r3;
     r0 /= M[0][0];
     x[0] = r0;
     x[1] = r1;
     x[2] = r2;
     x[3] = r3;
+    if (g_alt & ALT_NORM_SEQ) return sqrt(((r0 * r0 + r1 * r1) + r2 * r2) + r3 * r3);
     return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
 }
 
@@ -712,14 +740,15 @@ typedef struct {
     float fx, fy, cx, cy, fx_inv, fy_inv, k1, k2, p1, p2, k3;
     const float *KRK; /* mKRKinv, 3x3 row-major */
     float r31, r32, r33;
+    int single_homography; /* mPredictMethod == SINGLE_HOMOGRAPHY (:233-253) */
 } cam_t;
 
 static void predict_one(const cam_t *c, float rx, float ry, float *ux, float *uy, float *dxo, float *dyo)
 {
     float x_normal = (rx - c->cx) * c->fx_inv; /* :209-210 */
     float y_normal = (ry - c->cy) * c->fy_inv;
-    /* :216  1.0 / (float expr) -> double, narrowed */
-    float lambda = (float)(1.0 / (double)(c->r31 * x_normal + c->r32 * y_normal + c->r33));
+    /* :216  1.0 / (float expr) -> double, narrowed;  :235  float lambda = 1.0 */
+    float lambda = c->single_homography ? 1.0f : (float)(1.0 / (double)(c->r31 * x_normal + c->r32 * y_normal + c->r33));
     float pt_x = (c->KRK[0] * rx + c->KRK[1] * ry + c->KRK[2]) * lambda; /* :217 */
     float pt_y = (c->KRK[3] * rx + c->KRK[4] * ry + c->KRK[5]) * lambda; /* :218 */
     float x = (pt_x - c->cx) * c->fx_inv;                                /* :221-222 */
@@ -753,6 +782,7 @@ int pagk_oracle_gyro_predict(const pagk_params *cam, int32_t width, int32_t heig
     c.k3 = cam->n_dist_coef == 5 ? cam->dist_coef[4] : 0;
     c.KRK = KRKinv;
     c.r31 = r3[0], c.r32 = r3[1], c.r33 = r3[2];
+    c.single_homography = cam->predict_method == 2;
 
     const float hh = (float)half_patch;
     const float cornx[4] = {-hh, hh, -hh, hh}, corny[4] = {-hh, -hh, hh, hh}; /* :73-77 */

@@ -90,6 +90,11 @@ int pagk_oracle_geometry_validation(const double *H21, const double *H12, const 
                                     const float *pt_ref_un, const float *pt_predict_un, uint8_t *status,
                                     float sigma, float *track_score);
 
+/* tools/parity_risk.py only: switch ONE of the restatement's guesses about third-party arithmetic to its
+ * alternative (bit flags, see pagk_oracle.c) to measure how much the results depend on it.  0 restores the
+ * documented restatement.  Process-global; never used by tests or the benchmark. */
+void pagk_oracle_set_alternatives(uint32_t flags);
+
 /* ---- NCC nearest-neighbour matching ------------------------------------------- */
 /* Free NCC(halfPatchSize, ref, cur, pt_ref, pt_cur, warp_mat), src/utils.cpp:166-200, over the free
  * GetPixelValue of include/utils.h:32-46 (NOT PatchMatch::GetPixelValue).  A: 2x2 row-major or NULL (empty Mat). */

@@ -34,7 +34,7 @@ class Params(C.Structure):
         ("has_gyro_predict_initial", C.c_uint8), ("inverse", C.c_uint8),
         ("consider_illumination", C.c_uint8), ("consider_affine", C.c_uint8),
         ("regularization_penalty", C.c_uint8), ("calculate_ncc", C.c_uint8),
-        ("reserved0", C.c_uint8 * 2),
+        ("predict_method", C.c_uint8), ("reserved0", C.c_uint8 * 1),
         ("lambda_", C.c_float), ("alpha", C.c_float), ("max_distance", C.c_int32),
         ("inv_log_max_dist", C.c_float),
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
@@ -49,7 +49,7 @@ class Outputs(C.Structure):
 
 
 def make_params(*, half_patch=5, iterations=10, pyramids=3, has_gyro=True, illumination=True,
-                affine=True, penalty=False, ncc=False, inverse=False, camera=None) -> Params:
+                affine=True, penalty=False, ncc=False, inverse=False, camera=None, predict_method=1) -> Params:
     """pagk_params_default() (reference call site src/gyro_aided_tracker.cpp:276-282)
     with overrides.  `camera` is a synth.Camera or None."""
     p = Params()
@@ -60,6 +60,7 @@ def make_params(*, half_patch=5, iterations=10, pyramids=3, has_gyro=True, illum
     p.consider_affine = int(affine)
     p.regularization_penalty = int(penalty)
     p.calculate_ncc = int(ncc)
+    p.predict_method = int(predict_method)   # 1 PIXEL_AWARE_PREDICTION, 2 SINGLE_HOMOGRAPHY (gyro prediction only)
     p.lambda_, p.alpha, p.max_distance = 1.0, 0.5, 25
     p.inv_log_max_dist = 0.0
     if camera is not None:
@@ -157,6 +158,8 @@ def declare(lib) -> None:
     lib.pagk_set_stream.argtypes = [vp, vp]
     lib.pagk_set_kernel.restype = C.c_int
     lib.pagk_set_kernel.argtypes = [vp, i32]
+    lib.pagk_last_variant.restype = C.c_int
+    lib.pagk_last_variant.argtypes = [vp]
     lib.pagk_last_kernel_ms.restype = C.c_int
     lib.pagk_last_kernel_ms.argtypes = [vp, _P(C.c_float), _P(C.c_float)]
     lib.pagk_gyro_predict_device.restype = C.c_int
@@ -224,7 +227,7 @@ EXPORTED_SYMBOLS = [
     "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_track_device_fused", "pagk_sync",
-    "pagk_set_stream", "pagk_set_kernel", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
+    "pagk_set_stream", "pagk_set_kernel", "pagk_last_variant", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
     "pagk_gyro_predict_device_rot",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
     "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
@@ -467,6 +470,13 @@ class Context:
 
     def set_kernel(self, which: int):
         self._check(self.lib.pagk_set_kernel(self.h, which), "pagk_set_kernel")
+
+    VARIANT_NAMES = {0: "4-wave workgroup per feature, DPP row chains", 1: "one thread per feature (cross-check)",
+                     2: "2-wave workgroup per feature, f64 MFMA chain", 3: "one wave per feature, f64 MFMA chain",
+                     4: "relaxed order (experiment)", 5: "four features per wave, f64 MFMA blocks"}
+
+    def last_variant(self) -> int:
+        return int(self.lib.pagk_last_variant(self.h))
 
     def last_kernel_ms(self):
         t, p = C.c_float(0), C.c_float(0)

@@ -37,8 +37,7 @@ public:
     };
     enum ePredictMethod { PIXEL_AWARE_PREDICTION = 1, SINGLE_HOMOGRAPHY = 2 };
 
-    // reference include/gyro_aided_tracker.h:109-117 (the Frame-based constructor :119-126 needs
-    // Frame / IMU::Calib, which stay the host application's own types)
+    // reference include/gyro_aided_tracker.h:109-117
     GyroAidedTracker(double t, double t_ref, const cv::Mat &imgGrayRef_, const cv::Mat &imgGrayCur_,
                      const std::vector<cv::KeyPoint> &vKeysRef_, const std::vector<cv::KeyPoint> &vKeysCur_,
                      const std::vector<cv::KeyPoint> &vKeysUnRef_, const std::vector<cv::KeyPoint> &vKeysUnCur_,
@@ -47,6 +46,55 @@ public:
                      eType type_ = GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION,
                      ePredictMethod predictMethod_ = PIXEL_AWARE_PREDICTION, std::string saveFolderPath = "",
                      int halfPatchSize_ = 5);
+
+    // reference include/gyro_aided_tracker.h:119-126, src/gyro_aided_tracker.cpp:30-49: the constructor BOTH reference
+    // apps use (Examples/Demo/RealSenseD435i.cpp:244-254, Examples/ROS/.../feature_tracker.cpp).  Frame and IMU::Calib
+    // stay the host application's own types (out of scope), so the constructor is a template
+    // over them; any types with the fields the reference's initialiser list reads bind here:
+    //   FrameT: mTimeStamp, mGray, mvKeys, mvKeysUn, mvImuFromLastFrame, mpCameraParams->{mK, mDistCoef, width, height}
+    //   CalibT: Tbc (4x4 CV_32F; mRbc = its top-left 3x3, Tbc.colRange(0,3).rowRange(0,3) in the reference)
+    template <class FrameT, class CalibT>
+    GyroAidedTracker(const FrameT &pFrameRef, const FrameT &pFrameCur, const CalibT &imuCalib, const cv::Point3f &biasg_,
+                     const cv::Mat &normalizeTable_,
+                     eType type_ = GYRO_PREDICT_WITH_OPTICAL_FLOW_REFINED_CONSIDER_ILLUMINATION_DEFORMATION,
+                     ePredictMethod predictMethod_ = PIXEL_AWARE_PREDICTION, std::string saveFolderPath = "",
+                     int halfPatchSize_ = 5)
+        : mTimeStamp(pFrameCur.mTimeStamp), mTimeStampRef(pFrameRef.mTimeStamp), mImgGrayRef(pFrameRef.mGray),
+          mImgGrayCur(pFrameCur.mGray), mvKeysRef(pFrameRef.mvKeys), mvKeysRefUn(pFrameRef.mvKeysUn),
+          mvKeysCur(pFrameCur.mvKeys), mvKeysCurUn(pFrameCur.mvKeysUn), mvImuFromLastFrame(pFrameCur.mvImuFromLastFrame),
+          mHalfPatchSize(halfPatchSize_), mRbc(TopLeft3x3(imuCalib.Tbc)), mBias(biasg_), mK(pFrameCur.mpCameraParams->mK),
+          mDistCoef(pFrameCur.mpCameraParams->mDistCoef), mWidth(pFrameCur.mpCameraParams->width),
+          mHeight(pFrameCur.mpCameraParams->height), mNormalizeTable(normalizeTable_), mType(type_),
+          mPredictMethod(predictMethod_)
+    {
+        (void)saveFolderPath;  // result logging is out of scope
+        Initialize();
+    }
+
+    // reference include/gyro_aided_tracker.h:130, src/gyro_aided_tracker.cpp:97-111: the tracker's results handed back to
+    // the application's Frame (fields of include/frame.h that the demo loop reads, RealSenseD435i.cpp:255-300)
+    template <class FrameT>
+    void SetBackToFrame(FrameT &pFrame)
+    {
+        pFrame.mvPtGyroPredictUn = std::vector<cv::Point2f>(mvPtGyroPredictUn.begin(), mvPtGyroPredictUn.end());
+        pFrame.mvPtPredict = std::vector<cv::Point2f>(mvPtPredict.begin(), mvPtPredict.end());
+        pFrame.mvPtPredictUn = std::vector<cv::Point2f>(mvPtPredictUn.begin(), mvPtPredictUn.end());
+        pFrame.mvStatus = std::vector<cv::uchar>(mvStatus.begin(), mvStatus.end());
+        pFrame.mvNcc = std::vector<float>(mvNccAfterPatchMatched.begin(), mvNccAfterPatchMatched.end());
+        pFrame.mvvFlowsPredictCorners.resize(mvvFlowsPredictCorners.size());
+        for (size_t i = 0, iend = mvvFlowsPredictCorners.size(); i < iend; i++)
+            pFrame.mvvFlowsPredictCorners[i] =
+                std::vector<cv::Point2f>(mvvFlowsPredictCorners[i].begin(), mvvFlowsPredictCorners[i].end());
+        pFrame.mRcl = mRcl.clone();
+    }
+
+    static cv::Mat TopLeft3x3(const cv::Mat &T)
+    {
+        cv::Mat R(3, 3, cv::CV_32F);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) R.at<float>(r, c) = T.at<float>(r, c);
+        return R;
+    }
 
     void Initialize();
     void SetRegularizationPenalty(bool flag) { mbRegularizationPenalty = flag; }

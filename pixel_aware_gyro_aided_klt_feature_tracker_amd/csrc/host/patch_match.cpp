@@ -9,26 +9,36 @@
 #include "gyro_aided_tracker.h"
 
 namespace {
-thread_local pagk_ctx *g_ctx = nullptr;
-}
+// One context per host thread (the reference builds a PatchMatch per frame pair on whatever thread calls it, and a
+// PatchMatch is not re-entrant).  The holder's destructor runs at thread exit, so a worker thread that tracked a
+// few frames does not leak its HIP stream, device slots and pinned buffers; ReleaseContext() frees it earlier.
+struct CtxHolder {
+    pagk_ctx *ctx = nullptr;
+    ~CtxHolder()
+    {
+        if (ctx) pagk_destroy(ctx);
+    }
+};
+thread_local CtxHolder g_holder;
+}  // namespace
 
 pagk_ctx *PatchMatch::Context(int device)
 {
-    if (!g_ctx) {
-        int rc = pagk_create(&g_ctx, device);
+    if (!g_holder.ctx) {
+        int rc = pagk_create(&g_holder.ctx, device);
         if (rc != PAGK_OK) {
-            g_ctx = nullptr;
+            g_holder.ctx = nullptr;
             throw std::runtime_error(std::string("PatchMatch: pagk_create failed: ") + pagk_strerror(rc) +
                                      " (the HIP path is the only implementation; there is no CPU fallback)");
         }
     }
-    return g_ctx;
+    return g_holder.ctx;
 }
 
 void PatchMatch::ReleaseContext()
 {
-    if (g_ctx) pagk_destroy(g_ctx);
-    g_ctx = nullptr;
+    if (g_holder.ctx) pagk_destroy(g_holder.ctx);
+    g_holder.ctx = nullptr;
 }
 
 // reference src/patch_match.cpp:33-59

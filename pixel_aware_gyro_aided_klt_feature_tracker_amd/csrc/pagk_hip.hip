@@ -56,6 +56,7 @@ struct pagk_ctx {
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
+    int last_variant = -1;  // variant the last tracking launch used (pagk_last_variant)
     // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
     // the 4-wave DPP kernel is fastest while every workgroup is resident (its latency is lowest), the
     // 2-wave MFMA variant from ~2500 features, one wave per feature from ~10000.
@@ -312,6 +313,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool use_quad = mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->quad_min_features));
         const bool use_wave = !use_quad && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
         const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
+        ctx->last_variant = ctx->kernel == 1 ? 1 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
         } else if (use_quad) {
@@ -646,6 +648,8 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
     return PAGK_OK;
 }
 
+int pagk_last_variant(const pagk_ctx *ctx) { return ctx ? ctx->last_variant : PAGK_E_ARG; }
+
 int pagk_sync(pagk_ctx *ctx)
 {
     if (!ctx) return PAGK_E_ARG;
@@ -681,7 +685,12 @@ int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_
 {
     if (!ctx || slot < 0 || slot >= kUserSlots) return PAGK_E_ARG;
     NOT_WHILE_CAPTURING(ctx, "pagk_frame_upload");
-    return frame_upload_any(ctx, slot, img, pyramids);
+    int rc = frame_upload_any(ctx, slot, img, pyramids);
+    if (rc) return rc;
+    // the copy reads img->data asynchronously when that memory is pinned (a camera ring buffer, a pinned tensor):
+    // do not return before it has been read, or the caller could overwrite the frame while it is in flight
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
 }
 
 static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
@@ -895,6 +904,7 @@ static int gyro_predict_any(pagk_ctx *ctx, const pagk_params *params, int32_t wi
     memset(&a, 0, sizeof a);
     a.n = n, a.width = width, a.height = height;
     a.half = (float)params->half_patch;
+    a.single_homography = params->predict_method == 2;  // ePredictMethod SINGLE_HOMOGRAPHY
     a.fx = params->fx, a.fy = params->fy, a.cx = params->cx, a.cy = params->cy;
     a.fx_inv = (float)(1.0 / (double)params->fx);  // src/gyro_aided_tracker.cpp:66
     a.fy_inv = (float)(1.0 / (double)params->fy);

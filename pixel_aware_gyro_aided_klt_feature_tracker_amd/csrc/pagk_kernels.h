@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(PyrArgs a)
 // ---- GyroPredictFeatures (src/gyro_aided_tracker.cpp:118-185,194-231), one thread per feature ----
 struct PredictArgs {
     int n, width, height;
+    int single_homography;  // mPredictMethod == SINGLE_HOMOGRAPHY: lambda = 1 (:235)
     float half;  // (float)mHalfPatchSize
     float fx, fy, cx, cy, fx_inv, fy_inv, k1, k2, p1, p2, k3;
     float K[6];            // rows 0 and 1 of mKRKinv
@@ -182,13 +183,13 @@ struct PredictArgs {
     const float *d_rot;
 };
 
-// GyroPredictOnePixel, PIXEL_AWARE_PREDICTION (:205-231)
+// GyroPredictOnePixel (:194-256): PIXEL_AWARE_PREDICTION (:212-231) or SINGLE_HOMOGRAPHY (:233-253, lambda = 1.0)
 __device__ __forceinline__ void predict_one(const PredictArgs &a, float rx, float ry, float &ux, float &uy, float &dxo,
                                             float &dyo)
 {
     float x_normal = (rx - a.cx) * a.fx_inv;  // :209-210
     float y_normal = (ry - a.cy) * a.fy_inv;
-    float lambda = (float)(1.0 / (double)(a.r31 * x_normal + a.r32 * y_normal + a.r33));  // :216
+    float lambda = a.single_homography ? 1.0f : (float)(1.0 / (double)(a.r31 * x_normal + a.r32 * y_normal + a.r33));  // :216 / :235
     float pt_x = (a.K[0] * rx + a.K[1] * ry + a.K[2]) * lambda;                            // :217
     float pt_y = (a.K[3] * rx + a.K[4] * ry + a.K[5]) * lambda;                            // :218
     float x = (pt_x - a.cx) * a.fx_inv;                                                    // :221-222
@@ -615,7 +616,8 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #ifdef PAGK_STAMPS
         t0 = __builtin_amdgcn_s_memtime();
 #endif
-        const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
+        const DevLevel &L1 = a.l1[level];
+        const DevLevel L2 = pin_level(a.l2[level]);  // read by every iteration: scalar registers, not kernel-argument loads
         const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
         float nx, ny;
         if (level == a.n_levels - 1) {  // :180
@@ -659,8 +661,8 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
             const float gain = 1.0f + dg;
             // interior test (block-uniform): every tap coordinate of every pixel, +-1 included,
             // lies in [0, cols-1) x [0, rows-1) => clamps are no-ops and can be skipped.
-            const bool interior = (bx - ext_x >= 0.0f) && (bx + ext_x < L2.fcols_m1) &&
-                                  (by - ext_y >= 0.0f) && (by + ext_y < L2.frows_m1);
+            const bool interior = (bx - ext_x >= 0.0f) & (bx + ext_x < L2.fcols_m1) &
+                                  (by - ext_y >= 0.0f) & (by + ext_y < L2.frows_m1);
             // all rounds' gathers are issued before any is consumed (lanes past the patch sample
             // a valid pixel and simply do not store)
             FiveTaps taps[NR];

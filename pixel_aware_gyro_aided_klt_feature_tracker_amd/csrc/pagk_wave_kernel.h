@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
     float lastCost = 0.0f;
 
     for (int level = a.n_levels - 1; level >= 0; level--) {
-        const DevLevel &L1 = a.l1[level], &L2 = a.l2[level];
+        const DevLevel &L1 = a.l1[level];
+        const DevLevel L2 = pin_level(a.l2[level]);
         const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
         float nx, ny;
         if (level == a.n_levels - 1) {  // :180

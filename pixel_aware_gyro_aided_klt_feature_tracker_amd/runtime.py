@@ -40,6 +40,8 @@ class ResidentTracker:
         self._graphs = {}           # mode -> graph ids of the captured step ("graph": one; "fork", "fused": two)
         self._graph_failed = False  # capture was refused once: direct launches from then on
         self.mode_used = "serial"   # how the last step's launches were issued
+        self._gather_done = None    # event: the previous step's all-gather (side stream) has read self.out
+        self._last_gather = None
         self.n = 0
 
     def close(self):
@@ -141,10 +143,15 @@ class ResidentTracker:
           "fused"   the next frame's pyramid as trailing workgroups of the tracking launch itself
                     (pagk_track_device_fused), one single-node graph per parity: the pyramid costs no launch and no
                     gap.  Like "streams" it needs frame k+1 while pair (k-1, k) is tracked."""
+        gather = gather and not mode.endswith("-nogather")
+        mode = mode.replace("-nogather", "")
         graph = {"graph": True, "fork": "fork", "fused": "fused"}.get(mode, False)
         overlap = mode == "streams"
         if mode not in ("graph", "fork", "fused", "serial", "streams"):
             raise ValueError(mode)
+        collective = gather and (self.world > 1 or distributed.FORCE_COLLECTIVE)
+        if collective:
+            return self._sharded_step(mode)
         with torch.cuda.stream(self.main):
             if graph and not self._graph_failed:
                 try:
@@ -157,11 +164,13 @@ class ResidentTracker:
                     self._graph_failed = True
                     self._drop_graph()
                     self.ctx.set_stream(self.main.cuda_stream)
+                    self.mode_used = "serial"
                     self.rebuild_current_pyramid(1)
                     self.track_shard(1)
                 else:
                     self.mode_used = mode
             elif graph:
+                self.mode_used = "serial"
                 self.rebuild_current_pyramid(1)
                 self.track_shard(1)
             elif not overlap:
@@ -180,12 +189,72 @@ class ResidentTracker:
                 self._trk_done[slot] = done
                 self.cur_slot = 3 - slot                          # 1 <-> 2
                 self._pyr_ready = self._prefetch_pyramid(self.cur_slot)
-            if gather and (self.world > 1 or distributed.FORCE_COLLECTIVE):
-                res = distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
-                if isinstance(res, distributed.Gathered):
-                    self._gather_buf = res.raw
-                return res
         return {name: self.out[name][:self.hi - self.lo] for name, _, _ in distributed.FIELDS}
+
+    def _sharded_step(self, mode: str):
+        """A step of the sharded path (world > 1): pyramid, this rank's block of features, then the one exchange of
+        the path -- the all-gather of the packed result slices -- on the SIDE stream, so that it runs beside the next
+        step's pyramid; the next step's tracking launch waits for it (it rewrites the slice the gather reads, and in
+        a tracker its inputs derive from the gathered results, src/gyro_aided_tracker.cpp:289-341).  The tracking
+        launch is replayed from a one-node hipGraph when `mode` is a graph mode."""
+        with torch.cuda.stream(self.main):
+            self.rebuild_current_pyramid(1)                        # needs no result of the previous step
+            if self._gather_done is not None:
+                self.main.wait_event(self._gather_done)
+            if mode in ("graph", "fused", "fork") and not self._graph_failed:
+                if "track" not in self._graphs:
+                    self.track_shard(1)                            # warm-up
+                    self.main.synchronize()
+                    try:
+                        self.ctx.graph_begin()
+                        try:
+                            self.track_shard(1)
+                        finally:
+                            self._graphs["track"] = (self.ctx.graph_end(),)
+                    except capi.PagkError:
+                        self._graph_failed = True
+                        self._graphs.pop("track", None)
+                if "track" in self._graphs:
+                    self.ctx.graph_launch(self._graphs["track"][0])
+                    self.mode_used = "graph"
+                else:
+                    self.track_shard(1)
+                    self.mode_used = "serial"
+            else:
+                self.track_shard(1)
+                self.mode_used = "serial"
+            tracked = torch.cuda.Event()
+            tracked.record(self.main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(tracked)
+            res = distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
+            if isinstance(res, distributed.Gathered):
+                self._gather_buf = res.raw
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self._gather_done = done
+        self._last_gather = res
+        return res
+
+    def finish(self):
+        """Order everything issued so far (tracking on `main`, the last gather on `side`) before the caller's
+        stream-wide synchronisation."""
+        if self._gather_done is not None:
+            self.main.wait_event(self._gather_done)
+
+    def gather_report(self, reps: int = 20) -> dict:
+        """The all-gather by itself: average duration from events on the stream it runs on."""
+        ts = []
+        with torch.cuda.stream(self.side):
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+                distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
+                e1.record(self.side)
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+        return {"gather_ms": float(np.mean(ts[2:])) if len(ts) > 2 else float(np.mean(ts)),
+                "bytes_per_rank": int(self.out["_buf"].numel()), "ranks": self.world}
 
     def track_shard_fused(self, cur: int):
         """PatchMatch(0, cur) and, in the same launch, the pyramid of the next frame into the other slot."""
@@ -249,6 +318,6 @@ class ResidentTracker:
             self.cur_slot = 3 - self.cur_slot
 
     def synchronize(self):
-        """Wait for everything step() has issued (tracking on `main`, prefetch on `side`)."""
+        """Wait for everything step() has issued (tracking on `main`, prefetch / gather on `side`)."""
         self.main.synchronize()
         self.side.synchronize()

@@ -58,6 +58,24 @@ def test_shell_integrates_gyro_like_the_reference(built):
     assert ok.sum() > 30 and np.abs(out["pt_predict_un"][ok] - want[ok]).max() < 0.05
 
 
+def test_frame_based_constructor_and_set_back_to_frame(built, tmp_path):
+    """tests/frame_ctor_test.cpp: the constructor both reference apps use (include/gyro_aided_tracker.h:119-126) bound
+    to application-side Frame / CameraParams / IMU::Calib stand-ins, against the data constructor, and SetBackToFrame
+    (:130).  eType GYRO_PREDICT: host code only, runs without a GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = capi.PKG_DIR
+    exe = str(tmp_path / "frame_ctor_test")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), os.path.join(root, "tests", "frame_ctor_test.cpp"),
+                    "-o", exe, "-L", pkg, "-l:libpagk_tracker.so", "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "frame ctor ok" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("type_", [2, 3, 4, 5, 6])
 def test_shell_track_features_end_to_end(built, type_):

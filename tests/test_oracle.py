@@ -180,3 +180,32 @@ def test_oracle_under_address_and_ub_sanitizers(built, tmp_path):
                     os.path.join(root, "oracle", "pagk_oracle.c"), "-o", exe, "-lm", "-lpthread"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "asan driver ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_single_homography_prediction_is_the_pixel_aware_one_with_lambda_one(built):
+    """ePredictMethod SINGLE_HOMOGRAPHY (reference src/gyro_aided_tracker.cpp:233-253): the same arithmetic with
+    `float lambda = 1.0`.  Checked against a float32 restatement of the two lines that differ."""
+    import numpy as np
+    from oracle import pagk_oracle as orc
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
+    cam = synth.D435I
+    rng = np.random.default_rng(3)
+    pts = np.c_[rng.uniform(0, 640, 300), rng.uniform(0, 480, 300)].astype(np.float32)
+    R = synth.rodrigues(np.array((0.02, -0.03, 0.05))).astype(np.float32)
+    K = cam.K.astype(np.float32)
+    KRK = (K.astype(np.float64) @ R.astype(np.float64) @ np.linalg.inv(K.astype(np.float64))).astype(np.float32)
+    f32 = np.float32
+    for method in (1, 2):
+        p = capi.make_params(camera=cam, predict_method=method)
+        pu, pd, st, A = orc.gyro_predict(p, 640, 480, 5, KRK, R[2], pts)
+        for i in range(0, 300, 7):
+            x, y = pts[i]
+            xn, yn = f32(f32(x - f32(cam.cx)) * f32(1.0 / f32(cam.fx))), f32(f32(y - f32(cam.cy)) * f32(1.0 / f32(cam.fy)))
+            lam = f32(1.0) if method == 2 else f32(1.0 / float(f32(f32(f32(R[2, 0] * xn) + f32(R[2, 1] * yn)) + R[2, 2])))
+            ux = f32(f32(f32(f32(KRK[0, 0] * x) + f32(KRK[0, 1] * y)) + KRK[0, 2]) * lam)
+            uy = f32(f32(f32(f32(KRK[1, 0] * x) + f32(KRK[1, 1] * y)) + KRK[1, 2]) * lam)
+            inside = 0 <= ux < 640 and 0 <= uy < 480
+            if st[i]:
+                assert inside and pu[i, 0] == ux and pu[i, 1] == uy
+            else:
+                assert tuple(pu[i]) == (0.0, 0.0)

@@ -343,6 +343,89 @@ def test_gyro_predict_on_device_then_track_without_host_round_trip(ctx):
     assert_parity(got, ref, w.n, exact=True, what="device predict -> device track")
 
 
+def test_single_homography_prediction_on_device(ctx):
+    """ePredictMethod SINGLE_HOMOGRAPHY (reference src/gyro_aided_tracker.cpp:233-253: lambda = 1) on the device
+    against the oracle, and different from the pixel-aware prediction on the same inputs."""
+    cam = synth.EUROC
+    w = synth.config(1, n=800, edge_fraction=0.1)
+    Rp = synth.rodrigues(np.array((0.5, -1.0, 2.0)) * 0.05)
+    K32 = cam.K.astype(np.float32)
+
+    def mul(a, b):
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    KRK = mul(mul(K32, Rp.astype(np.float32)), np.linalg.inv(K32.astype(np.float64)).astype(np.float32))
+    r3 = Rp.astype(np.float32)[2]
+    dev = torch.device("cuda", 0)
+    d_ref = torch.from_numpy(w.pt_ref).to(dev)
+    res = {}
+    for method in (1, 2):
+        p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, camera=cam,
+                             predict_method=method)
+        pu, pd, st, A = orc.gyro_predict(p, 752, 480, w.half_patch, KRK, r3, w.pt_ref)
+        d_pu = torch.full((w.n, 2), 7.0, device=dev)
+        d_pd = torch.full((w.n, 2), 7.0, device=dev)
+        d_st = torch.full((w.n,), 9, dtype=torch.uint8, device=dev)
+        d_A = torch.zeros((w.n, 4), device=dev)
+        ctx.gyro_predict_device(p, 752, 480, KRK, r3, w.n, d_ref, d_pu, d_pd, d_st, d_A)
+        ctx.sync()
+        assert np.array_equal(d_st.cpu().numpy(), st) and 0 < int(st.sum())
+        assert np.array_equal(d_pu.cpu().numpy(), pu) and np.array_equal(d_pd.cpu().numpy(), pd)
+        assert np.array_equal(d_A.cpu().numpy()[st > 0], A[st > 0])
+        res[method] = pu
+    assert not np.array_equal(res[1], res[2])
+
+
+# ---- every BASELINE config at its own size (SURVEY.md section 8(d)) ---------------------------------
+def test_config4_stream_shape_at_full_size(ctx):
+    """BASELINE configs[4]: one 1280x720 stream x 4000 keypoints.  The launch auto-selects the 2-wave MFMA variant
+    (>= 2500 features); checked against the oracle on a seeded subset of the features and, over all 4000, through
+    size-independent properties: determinism, and invariance under a permutation of the feature order."""
+    w = synth.config(4)
+    assert w.img_ref.shape == (720, 1280) and w.n == 4000
+    p = params_for(w)
+    a = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert ctx.last_variant() == 2
+    b = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    for k in ("pt_un", "pt_dist", "status", "pix_err", "dist_pred", "iters"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"non-deterministic {k}"
+    rng = np.random.default_rng(4)
+    sub = np.sort(rng.choice(w.n, 600, replace=False))
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref[sub].copy(), w.pt_init[sub].copy(), w.affine[sub].copy(),
+                    w.status_in[sub].copy(), nthreads=16)
+    assert_parity({k: v[sub] for k, v in a.items()}, ref, 600, exact=True, what="configs[4] subset vs oracle")
+    perm = rng.permutation(w.n)
+    c = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref[perm].copy(), w.pt_init[perm].copy(), w.affine[perm].copy(),
+                  w.status_in[perm].copy())
+    for k in ("pt_un", "status", "pix_err", "iters"):
+        assert np.array_equal(c[k][:w.n], a[k][:w.n][perm], equal_nan=True), f"{k} depends on the feature order"
+    assert int(a["status"][:w.n].sum()) > 0.8 * w.n_active
+
+
+def test_config4_eight_concurrent_streams_on_one_gpu(ctx):
+    """BASELINE configs[4] in its 8-stream form on ONE GPU: eight resident trackers of the 1280x720 x 4000 shape, each
+    with its own streams and hipGraph, stepped interleaved (two frames each); every stream must reproduce the
+    single-stream result bit for bit."""
+    w = synth.config(4)
+    p = params_for(w)
+    single = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    cams = []
+    for _ in range(8):
+        rt = runtime.ResidentTracker(p, device=0)
+        rt.load_pair(w.img_ref, w.img_cur)
+        rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+        cams.append(rt)
+    outs = None
+    for _ in range(2):
+        outs = [rt.step(mode="graph") for rt in cams]
+    torch.cuda.synchronize()
+    for k, (rt, out) in enumerate(zip(cams, outs)):
+        got = distributed.to_numpy(out)
+        assert rt.mode_used == "graph" and rt.ctx.last_variant() == 2
+        assert_parity(got, single, w.n, exact=True, what=f"stream {k} of 8")
+    for rt in cams:
+        rt.close()
+
+
 # ---- full-size properties (sizes the oracle would take too long to check in full) ---------------
 def test_full_size_properties_1080p_20000(ctx):
     w = synth.config(3)  # 1920x1080, 20000 keypoints

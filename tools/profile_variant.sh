@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 of ONE tracking variant on ONE workload (via tools/run_once.py): kernel trace + separate --pmc passes.
+# Usage (through gpurun):  bash tools/profile_variant.sh <tag> <config> <n> <kernel>     -> gpurun_out/prof_<tag>/
+# Then: python tools/save_profile_variant.py <tag>   copies kernel_stats.csv + pmc_summary.json into profiles/<tag>/.
+set -o pipefail
+TAG=$1; CFG=$2; N=$3; KERN=$4
+export TMPDIR=/tmp
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+run() { python3 $REPO/tools/run_once.py $CFG $N $KERN; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/tools/run_once.py $CFG $N $KERN 20 > $OUT/trace.log 2>&1 || exit 1
+pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $REPO/tools/run_once.py $CFG $N $KERN 6 > $OUT/$name.log 2>&1 || echo "pass $name failed" >> $OUT/failed.txt; }
+pass pmc_fetch FETCH_SIZE
+pass pmc_write WRITE_SIZE
+pass pmc_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_WAVE_CYCLES
+pass pmc_sq2 SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
+pass pmc_sq3 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_VALU_MFMA_BUSY_CYCLES
+pass pmc_ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+pass pmc_tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum
+pass pmc_l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+ls $OUT
