@@ -191,6 +191,12 @@ def main() -> int:
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)   # before anything touches the GPU in this process
 
+    # stdout carries exactly ONE line, the JSON: whatever libraries print while they initialise (RCCL's version
+    # banner, for one) is sent to stderr, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -389,7 +395,8 @@ def main() -> int:
             st_bad = int(np.count_nonzero(res["status"][:n] != ref["status"][:n]))
             d = np.abs(res["pt_un"][:n].astype(np.float64) - ref["pt_un"][:n].astype(np.float64))
             line["px_err_vs_cpu"] = {"max": float(d.max()), "status_mismatches": st_bad}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     rt.close()
     if comm is not None:

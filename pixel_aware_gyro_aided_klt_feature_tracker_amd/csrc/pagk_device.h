@@ -54,27 +54,12 @@ struct TrackArgs {
     float fx, fy, cx, cy, fx_inv, fy_inv, k1, k2, p1, p2, k3;
 };
 
-// A level's description copied out of the kernel-argument segment ONCE and pinned in scalar registers.  Without
-// the pin the compiler treats these fields as re-loadable and, short of SGPRs, re-fetches them inside the
-// Gauss-Newton loop: four dependent s_load / s_waitcnt round trips (~200 cycles each) in front of every
-// iteration's gathers (measured with the phase stamps: 1.3 k of a lone workgroup's 3.3 k sampling cycles).
-__device__ __forceinline__ DevLevel pin_level(const DevLevel &src)
-{
-    DevLevel L = src;
-#ifdef PAGK_NO_PIN  // A/B builds only
-    return L;
-#endif
-    unsigned long long q = (unsigned long long)(uintptr_t)L.quad;
-    asm volatile("" : "+s"(q));
-    L.quad = reinterpret_cast<const uint32_t *>((uintptr_t)q);
-    asm volatile("" : "+s"(L.cols));
-    asm volatile("" : "+s"(L.rows));
-    asm volatile("" : "+s"(L.fcols));
-    asm volatile("" : "+s"(L.frows));
-    asm volatile("" : "+s"(L.fcols_m1));
-    asm volatile("" : "+s"(L.frows_m1));
-    return L;
-}
+// A level's description copied out of the kernel-argument segment.  Pinning the fields in scalar registers with
+// `asm volatile("" : "+s"(x))` (so that the compiler cannot re-fetch them with s_load inside the Gauss-Newton loop)
+// was measured and dropped: the extra live SGPRs spill into VGPR lanes and the launch got 2-3 % slower (126.0 vs
+// 123.0 us at 1000 features, 312 vs 304 us at 4000; profiles/r02_ab_runs.md).  The re-fetches are issued early and
+// their latency is covered by the coordinate arithmetic.
+__device__ __forceinline__ DevLevel pin_level(const DevLevel &src) { return src; }
 
 // ---- bilinear sampler ---------------------------------------------------------------------------
 // One coordinate of PatchMatch::GetPixelValue (src/patch_match.cpp:394-401): clamp, integer

@@ -86,7 +86,9 @@ def test_bench_forced_collective_reports_the_gather():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "3", "--no-extras",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    b = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"exactly one JSON line on stdout, got {lines[:3]}"
+    b = json.loads(lines[0])
     g = b["gather"]
     assert g["gather_ms"] > 0 and g["ranks"] == 1 and "pagk_multi_allgather" in g["via"]
     assert g["ms_per_step_without_gather"] > 0 and b["value"] > 0
