@@ -44,6 +44,7 @@ struct TrackArgs {
     float *ncc;
     int *iters;
     unsigned long long *dbg;  // diagnostic builds only (PAGK_STAMPS)
+    float *ws;                // k_track_quad: per-wave scratch for the iteration-invariant img1 samples
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)
@@ -102,7 +103,21 @@ __device__ __forceinline__ float bilerp(uint32_t q, const Coord &cx, const Coord
     return cy.omf * top + cy.f * bot;
 }
 
-// ---- packed-f32 form of the sampler (PAGK_PK_BILERP), optionally with typed tap loads (PAGK_TYPED_TAPS) --------
+// ---- the sampler's two hardware-specific forms -------------------------------------------------------------------
+// Default build: tap loads through a typed buffer resource (the texture addresser converts the four bytes to floats)
+// and the interpolation in packed f32 (the quad's two rows side by side in v_pk_mul_f32 / v_pk_add_f32).  Both are
+// bit-identical to the classic form (byte unpacking with v_cvt_f32_ubyte, scalar f32 arithmetic), which
+// -DPAGK_CLASSIC_SAMPLER builds for A/B runs.  Measured on MI355X (same-session A/B, profiles/r02_ab_runs.md): 53
+// instead of 135 VALU instructions per patch pixel; -1.6 % launch time at 1000 features (the launch is latency-bound
+// there), -5 % at 20000 (four features per wave), -7.5 % at 8000.
+#if !defined(PAGK_CLASSIC_SAMPLER)
+#ifndef PAGK_PK_BILERP
+#define PAGK_PK_BILERP
+#endif
+#ifndef PAGK_TYPED_TAPS
+#define PAGK_TYPED_TAPS
+#endif
+#endif
 typedef float pagk_f32x4 __attribute__((ext_vector_type(4)));
 typedef float pagk_f32x2 __attribute__((ext_vector_type(2)));
 typedef int pagk_i32x4 __attribute__((ext_vector_type(4)));
@@ -208,9 +223,10 @@ struct Five {
 // their first use: sample5_issue computes the six coordinates and issues the five tap loads, sample5_finish
 // interpolates.
 #ifdef PAGK_PK_BILERP
+// five tap loads in flight and the six fractions; the (1 - xx, xx) pairs are formed at use
 struct FiveTaps {
     Taps q0, q1, q2, q3, q4;
-    pagk_f32x2 cx, cxp, cxm, cy, cyp, cym;
+    float fx, fxp, fxm, fy, fyp, fym;
 };
 template <bool CLAMP>
 __device__ __forceinline__ FiveTaps sample5_issue(const DevLevel &L, float X, float Y)
@@ -230,52 +246,66 @@ __device__ __forceinline__ FiveTaps sample5_issue(const DevLevel &L, float X, fl
     t.q2 = load_taps(ts, rc + cxm.i);
     t.q3 = load_taps(ts, rp + cx.i);
     t.q4 = load_taps(ts, rm + cx.i);
-    t.cx = cx.w, t.cxp = cxp.w, t.cxm = cxm.w, t.cy = cy.w, t.cyp = cyp.w, t.cym = cym.w;
+    t.fx = cx.w.y, t.fxp = cxp.w.y, t.fxm = cxm.w.y, t.fy = cy.w.y, t.fyp = cyp.w.y, t.fym = cym.w.y;
     return t;
+}
+__device__ __forceinline__ pagk_f32x2 weights_pk(float f)
+{
+    pagk_f32x2 w;
+    w.x = 1.0f - f;
+    w.y = f;
+    return w;
 }
 __device__ __forceinline__ Five sample5_finish(const FiveTaps &t)
 {
+    const pagk_f32x2 cx = weights_pk(t.fx), cxp = weights_pk(t.fxp), cxm = weights_pk(t.fxm);
+    const pagk_f32x2 cy = weights_pk(t.fy), cyp = weights_pk(t.fyp), cym = weights_pk(t.fym);
     Five r;
-    r.c = bilerp_pk(taps_f32(t.q0), t.cx, t.cy);
-    r.xp = bilerp_pk(taps_f32(t.q1), t.cxp, t.cy);
-    r.xm = bilerp_pk(taps_f32(t.q2), t.cxm, t.cy);
-    r.yp = bilerp_pk(taps_f32(t.q3), t.cx, t.cyp);
-    r.ym = bilerp_pk(taps_f32(t.q4), t.cx, t.cym);
+    r.c = bilerp_pk(taps_f32(t.q0), cx, cy);
+    r.xp = bilerp_pk(taps_f32(t.q1), cxp, cy);
+    r.xm = bilerp_pk(taps_f32(t.q2), cxm, cy);
+    r.yp = bilerp_pk(taps_f32(t.q3), cx, cyp);
+    r.ym = bilerp_pk(taps_f32(t.q4), cx, cym);
     return r;
 }
 #else
+// five packed quads and the six fractions: 11 registers between issue and use (1 - xx is recomputed at use: the
+// same single rounding)
 struct FiveTaps {
     uint32_t q0, q1, q2, q3, q4;
-    Coord cx, cxp, cxm, cy, cyp, cym;
+    float fx, fxp, fxm, fy, fyp, fym;
 };
 template <bool CLAMP>
 __device__ __forceinline__ FiveTaps sample5_issue(const DevLevel &L, float X, float Y)
 {
-    FiveTaps t;
-    t.cx = prep_coord<CLAMP>(X, L.fcols, L.fcols_m1);
-    t.cxp = prep_coord<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
-    t.cxm = prep_coord<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
-    t.cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
-    t.cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
-    t.cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
-    const int rc = __mul24(t.cy.i, L.cols), rp = __mul24(t.cyp.i, L.cols), rm = __mul24(t.cym.i, L.cols);
+    const Coord cx = prep_coord<CLAMP>(X, L.fcols, L.fcols_m1);
+    const Coord cxp = prep_coord<CLAMP>(X + 1.0f, L.fcols, L.fcols_m1);
+    const Coord cxm = prep_coord<CLAMP>(X - 1.0f, L.fcols, L.fcols_m1);
+    const Coord cy = prep_coord<CLAMP>(Y, L.frows, L.frows_m1);
+    const Coord cyp = prep_coord<CLAMP>(Y + 1.0f, L.frows, L.frows_m1);
+    const Coord cym = prep_coord<CLAMP>(Y - 1.0f, L.frows, L.frows_m1);
+    const int rc = __mul24(cy.i, L.cols), rp = __mul24(cyp.i, L.cols), rm = __mul24(cym.i, L.cols);
     const uint32_t *q = L.quad;
+    FiveTaps t;
     // unsigned 32-bit element offsets: SGPR base + VGPR offset addressing, no 64-bit pointer math
-    t.q0 = q[(uint32_t)(rc + t.cx.i)];
-    t.q1 = q[(uint32_t)(rc + t.cxp.i)];
-    t.q2 = q[(uint32_t)(rc + t.cxm.i)];
-    t.q3 = q[(uint32_t)(rp + t.cx.i)];
-    t.q4 = q[(uint32_t)(rm + t.cx.i)];
+    t.q0 = q[(uint32_t)(rc + cx.i)];
+    t.q1 = q[(uint32_t)(rc + cxp.i)];
+    t.q2 = q[(uint32_t)(rc + cxm.i)];
+    t.q3 = q[(uint32_t)(rp + cx.i)];
+    t.q4 = q[(uint32_t)(rm + cx.i)];
+    t.fx = cx.f, t.fxp = cxp.f, t.fxm = cxm.f, t.fy = cy.f, t.fyp = cyp.f, t.fym = cym.f;
     return t;
 }
 __device__ __forceinline__ Five sample5_finish(const FiveTaps &t)
 {
+    const Coord cx{0, t.fx, 1.0f - t.fx}, cxp{0, t.fxp, 1.0f - t.fxp}, cxm{0, t.fxm, 1.0f - t.fxm};
+    const Coord cy{0, t.fy, 1.0f - t.fy}, cyp{0, t.fyp, 1.0f - t.fyp}, cym{0, t.fym, 1.0f - t.fym};
     Five r;
-    r.c = bilerp(t.q0, t.cx, t.cy);
-    r.xp = bilerp(t.q1, t.cxp, t.cy);
-    r.xm = bilerp(t.q2, t.cxm, t.cy);
-    r.yp = bilerp(t.q3, t.cx, t.cyp);
-    r.ym = bilerp(t.q4, t.cx, t.cym);
+    r.c = bilerp(t.q0, cx, cy);
+    r.xp = bilerp(t.q1, cxp, cy);
+    r.xm = bilerp(t.q2, cxm, cy);
+    r.yp = bilerp(t.q3, cx, cyp);
+    r.ym = bilerp(t.q4, cx, cym);
     return r;
 }
 #endif

@@ -47,6 +47,8 @@ struct pagk_ctx {
     FrameSlot slots[kSlots];
     FeatBuf feat;
     FeatBuf score;  // scratch of the host-buffer geometry scoring path
+    void *quad_ws = nullptr;  // k_track_quad: iteration-invariant img1 samples, 4 * NCH * 64 floats per wave
+    size_t quad_ws_bytes = 0;
     // hipGraph capture of the per-frame work (pagk_graph_*): while capturing, nothing may allocate and the
     // timing events are left out (an event recorded into a graph cannot be read back)
     bool capturing = false;
@@ -62,7 +64,7 @@ struct pagk_ctx {
     // 2-wave MFMA variant from ~2500 features, one wave per feature from ~10000.
     int mfma_min_features = 2500;   // PAGK_MFMA_MIN
     int wave_min_features = 10000;  // PAGK_WAVE_MIN
-    int quad_min_features = 1 << 30;  // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
+    int quad_min_features = 8000;   // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h); profiles/r02_ab_runs.md
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
@@ -317,6 +319,20 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
         } else if (use_quad) {
+            const int nch = (Pm + 63) / 64;
+            const size_t need = (size_t)((n + 3) / 4) * 4 * nch * 64 * sizeof(float);
+            if (need > ctx->quad_ws_bytes) {
+                if (ctx->capturing) {
+                    snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
+                    return PAGK_E_ARG;
+                }
+                if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
+                ctx->quad_ws = nullptr;
+                ctx->quad_ws_bytes = 0;
+                HIPCHK(ctx, hipMalloc(&ctx->quad_ws, need));
+                ctx->quad_ws_bytes = need;
+            }
+            a.ws = static_cast<float *>(ctx->quad_ws);
             auto launch = [&](auto kern) -> hipError_t {
                 hipLaunchKernelGGL(kern, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, a);
                 return hipGetLastError();
@@ -626,6 +642,7 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->feat.block) (void)hipFree(ctx->feat.block);
     if (ctx->feat.host) (void)hipHostFree(ctx->feat.host);
     if (ctx->score.block) (void)hipFree(ctx->score.block);
+    if (ctx->quad_ws) (void)hipFree(ctx->quad_ws);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
         if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);

@@ -665,44 +665,52 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
                                   (by - ext_y >= 0.0f) & (by + ext_y < L2.frows_m1);
             // all rounds' gathers are issued before any is consumed (lanes past the patch sample
             // a valid pixel and simply do not store)
-            FiveTaps taps[NR];
+            // the gathers of up to two rounds are in flight at a time (a tap costs up to four registers until it is
+            // interpolated): NR = 2 issues everything up front, NR = 4 works in two groups
+            constexpr int G = NR < 2 ? NR : 2;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                float X = bx + wx[r], Y = by + wy[r];
-                taps[r] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
-            }
+            for (int r0 = 0; r0 < NR; r0 += G) {
+                FiveTaps taps[G];
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    const int r = r0 + u < NR ? r0 + u : NR - 1;
+                    float X = bx + wx[r], Y = by + wy[r];
+                    taps[u] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+                }
 #ifdef PAGK_STAMPS
-            STAMP(8)   // coordinates computed, gathers issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(9)   // gathers returned
+                if (r0 == 0) {
+                    STAMP(8)   // coordinates computed, gathers issued
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    STAMP(9)   // gathers returned
+                }
 #endif
-            Five smp[NR];
 #pragma unroll
-            for (int r = 0; r < NR; r++) smp[r] = sample5_finish(taps[r]);
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                int p = tid + kBlock * r;
-                if (p < P) {
-                    const Five &s = smp[r];
-                    float e = s.c + db - gain * s1[r];   // :252-253
-                    float Ix = 0.5f * (s.xp - s.xm);     // :259-260
-                    float Iy = 0.5f * (s.yp - s.ym);     // :261-262
-                    double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
-                    if constexpr (MFMA) {
-                        stream[0 * PS + p] = dIx;
-                        stream[1 * PS + p] = dIy;
-                        stream[2 * PS + p] = -de;
-                    } else {
-                        stream[0 * PP + p] = dIx * dIx;
-                        stream[1 * PP + p] = dIy * dIx;
-                        stream[2 * PP + p] = dIy * dIy;
-                        stream[3 * PP + p] = dIx * de;
-                        stream[4 * PP + p] = dIy * de;
-                        stream[5 * PP + p] = dIx;
-                        stream[6 * PP + p] = dIy;
-                        stream[7 * PP + p] = de;
+                for (int u = 0; u < G; u++) {
+                    const int r = r0 + u;
+                    if (r >= NR) continue;
+                    const Five s = sample5_finish(taps[u]);
+                    const int p = tid + kBlock * r;
+                    if (p < P) {
+                        float e = s.c + db - gain * s1[r];   // :252-253
+                        float Ix = 0.5f * (s.xp - s.xm);     // :259-260
+                        float Iy = 0.5f * (s.yp - s.ym);     // :261-262
+                        double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
+                        if constexpr (MFMA) {
+                            stream[0 * PS + p] = dIx;
+                            stream[1 * PS + p] = dIy;
+                            stream[2 * PS + p] = -de;
+                        } else {
+                            stream[0 * PP + p] = dIx * dIx;
+                            stream[1 * PP + p] = dIy * dIx;
+                            stream[2 * PP + p] = dIy * dIy;
+                            stream[3 * PP + p] = dIx * de;
+                            stream[4 * PP + p] = dIy * de;
+                            stream[5 * PP + p] = dIx;
+                            stream[6 * PP + p] = dIy;
+                            stream[7 * PP + p] = de;
+                        }
+                        esq[p] = e * e;  // :294
                     }
-                    esq[p] = e * e;  // :294
                 }
             }
 #ifdef PAGK_STAMPS

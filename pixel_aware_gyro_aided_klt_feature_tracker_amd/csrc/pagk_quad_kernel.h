@@ -69,15 +69,14 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         return;
     }
 
-    // lane -> patch pixel of chunk c: p = 64 c + lane, row-major (y outer, :233-234); x and y as two int16
-    int pxy[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    // lane -> patch pixel of chunk c: p = 64 c + lane, row-major (y outer, :233-234)
+    auto patch_xy = [&](int c, float &x, float &y) {
         int p = 64 * c + lane;
         p = p < P ? p : P - 1;
         const int yy = p / Wd, xx = p - yy * Wd;
-        pxy[c] = ((xx - h) & 0xffff) | ((yy - h) << 16);
-    }
+        x = (float)(xx - h);
+        y = (float)(yy - h);
+    };
 
     // MFMA operand roles of this lane (layout measured: A(q,i,k) in lane 16k+4q+i, B(q,k,j) in lane 16k+4q+j,
     // D(q,i,j) in lane 16i+4q+j): k = pixel within the group of four, q = block = feature, i = entry.
@@ -112,14 +111,15 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         // img1 samples are iteration-invariant (bit-identical to :253, :263): once per level, for all four features
         const float cneg = -sample<true>(L1, ptx, pty);
         const double cd = (double)cneg;
-        float s1[4][NCH];
-#pragma unroll
+        // ... kept in this wave's slice of the global workspace (4 x NCH x 64 floats, read back coalesced, one load
+        // per sampled pixel): 28 registers at h = 10 that would otherwise spill
+        float *ws = a.ws + (size_t)blockIdx.x * (4 * NCH * 64) + lane;
         for (int f = 0; f < 4; f++) {
             const float fx = rl(ptx, 16 * f), fy = rl(pty, 16 * f);
-#pragma unroll
             for (int c = 0; c < NCH; c++) {
-                const float x = (float)(short)(pxy[c] & 0xffff), y = (float)(pxy[c] >> 16);
-                s1[f][c] = sample<true>(L1, fx + x, fy + y);
+                float x, y;
+                patch_xy(c, x, y);
+                ws[(f * NCH + c) * 64] = sample<true>(L1, fx + x, fy + y);
             }
         }
         __syncthreads();  // the previous level's readers of cconst are done
@@ -138,13 +138,15 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             double d = 0.0;      // the four 4x4 accumulators (:217-218 H = 0, b = 0)
             float carry = 0.0f;  // cost = 0 (:283)
 
-#pragma unroll
+#pragma nounroll
             for (int c = 0; c < NCH; c++) {
                 // ---- sampling: chunk c of every active feature --------------------------------------
-                const float x = (float)(short)(pxy[c] & 0xffff), y = (float)(pxy[c] >> 16);
+                float x, y;
+                patch_xy(c, x, y);
                 const bool valid = 64 * c + lane < P;
-                for (int f = 0; f < 4; f++) {
-                    if (!((actm >> (16 * f)) & 1ull)) continue;  // wave-uniform
+                // the active features of the wave, in order (wave-uniform); the gathers of feature k+1 are issued
+                // before feature k's are consumed, so that a round's latency hides behind the previous round's math
+                auto issue = [&](int f, FiveTaps &tp, float &s1v) {
                     const int src = 16 * f;
                     float wx = x, wy = y;
                     if (a.use_affine) {  // :203-204
@@ -152,15 +154,43 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                         wy = rl(A10, src) * x + rl(A11, src) * y;
                     }
                     const float X = rl(bx, src) + wx, Y = rl(by, src) + wy;
-                    const Five s = ((intm >> src) & 1ull) ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
-                    const float s1v = f == 0 ? s1[0][c] : (f == 1 ? s1[1][c] : (f == 2 ? s1[2][c] : s1[3][c]));
-                    const float e = s.c + rl(db, src) - rl(gain, src) * s1v;  // :252-253
-                    const float Ix = 0.5f * (s.xp - s.xm);                     // :259-260
-                    const float Iy = 0.5f * (s.yp - s.ym);                     // :261-262
+                    tp = ((intm >> src) & 1ull) ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+                    s1v = ws[(f * NCH + c) * 64];
+                };
+                int f = __builtin_ctzll(actm) >> 4;            // first active feature
+                unsigned long long rest = actm & ~(0xffffull << (16 * f));
+                FiveTaps cur;
+                float s1cur;
+                issue(f, cur, s1cur);
+                while (true) {
+                    const int fn = rest ? (__builtin_ctzll(rest) >> 4) : -1;
+                    FiveTaps nxt;
+                    float s1nxt = 0.0f;
+#ifndef PAGK_QUAD_NO_PIPE
+                    if (fn >= 0) {
+                        rest &= ~(0xffffull << (16 * fn));
+                        issue(fn, nxt, s1nxt);
+                    }
+#endif
+                    const int src = 16 * f;
+                    const Five s = sample5_finish(cur);
+#ifdef PAGK_QUAD_NO_PIPE
+                    if (fn >= 0) {
+                        rest &= ~(0xffffull << (16 * fn));
+                        issue(fn, nxt, s1nxt);
+                    }
+#endif
+                    const float e = s.c + rl(db, src) - rl(gain, src) * s1cur;  // :252-253
+                    const float Ix = 0.5f * (s.xp - s.xm);                       // :259-260
+                    const float Iy = 0.5f * (s.yp - s.ym);                       // :261-262
                     S.chunk[0][f][lane] = (double)Ix;
                     S.chunk[1][f][lane] = (double)Iy;
                     S.chunk[2][f][lane] = -(double)e;
                     S.sq[f * 129 + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
+                    if (fn < 0) break;
+                    f = fn;
+                    cur = nxt;
+                    s1cur = s1nxt;
                 }
                 if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
