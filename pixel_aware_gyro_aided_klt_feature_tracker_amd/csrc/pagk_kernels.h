@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
 //                   the product of two f32-valued doubles is exact.  pagk_chain_asm.h;
 //   3. solve     -- one lane: penalty, 4x4 LLT, two triangular solves, norm;
 //   4. update    -- every lane applies the same update and takes the same exit (:322-343).
-// Dynamic LDS: double stream[8][PP]; float esq[PP]; double cslot[2]; double acc[16];
+// Dynamic LDS: double stream[8][PP + 1]; float esq[PP]; double cslot[2]; double acc[16];
 //              double upd[5]; float cost[2]      with PP = 32 * ceil(P / 32).
 //
 // MFMA variant (template MFMA = true, 2 waves): for launches with more features than the chip can
@@ -429,7 +429,7 @@ __host__ __device__ inline int track_block_pp(int half)
 __host__ __device__ inline size_t track_block_lds_bytes(int half)
 {
     size_t PP = (size_t)track_block_pp(half);
-    return kStreams * PP * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;
+    return kStreams * (PP + 1) * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;  // streams PP + 1 doubles apart
 }
 // MFMA variant: three f64 streams of PP + 8 (the +8 staggers the banks of neighbouring arrays),
 // X = Ix, Y = Iy, NE = -e, written per iteration, followed by a 16-double constant area
@@ -515,7 +515,11 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
     const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
     const int nfull = P / 32;  // P mod 32 == TAIL
 
-    const int PS = MFMA ? PP + 8 : PP;  // array stride in doubles
+    // array stride in doubles.  DPP variant: PP + 1, so that neighbouring streams start 8 bytes apart modulo the
+    // 256-byte bank span: the two rows of a 32-lane LDS group (lanes 0-15 / 16-31 read 16 bytes per lane of two
+    // DIFFERENT streams) then use complementary banks.  With a stride of PP (a multiple of 256 bytes) every chain
+    // read was a 2-way bank conflict (round 1: 0.82 conflict cycles per LDS instruction).
+    const int PS = MFMA ? PP + 8 : PP + 1;
     double *stream = reinterpret_cast<double *>(lds_raw);
     double *cst = stream + (size_t)kStreams * PS;  // MFMA variant: constant area (16 doubles)
     float *esq = reinterpret_cast<float *>(cst + (MFMA ? 16 : 0));
@@ -570,7 +574,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
         row_addr = lds_off(esq) + 8u * lr;  // cost rows (MFMA variant: wave 1, all four rows)
         row_inc = 128u;
     } else if (cid < 11) {
-        row_addr = lds_off(stream + (size_t)stream_of[cid] * PP) + 16u * lr;
+        row_addr = lds_off(stream + (size_t)stream_of[cid] * PS) + 16u * lr;
         row_inc = 256u;
     } else {
         row_addr = lds_off(cslot);  // every lane re-reads (c, c)
@@ -700,14 +704,14 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
                             stream[1 * PS + p] = dIy;
                             stream[2 * PS + p] = -de;
                         } else {
-                            stream[0 * PP + p] = dIx * dIx;
-                            stream[1 * PP + p] = dIy * dIx;
-                            stream[2 * PP + p] = dIy * dIy;
-                            stream[3 * PP + p] = dIx * de;
-                            stream[4 * PP + p] = dIy * de;
-                            stream[5 * PP + p] = dIx;
-                            stream[6 * PP + p] = dIy;
-                            stream[7 * PP + p] = de;
+                            stream[0 * PS + p] = dIx * dIx;
+                            stream[1 * PS + p] = dIy * dIx;
+                            stream[2 * PS + p] = dIy * dIy;
+                            stream[3 * PS + p] = dIx * de;
+                            stream[4 * PS + p] = dIy * de;
+                            stream[5 * PS + p] = dIx;
+                            stream[6 * PS + p] = dIy;
+                            stream[7 * PS + p] = de;
                         }
                         esq[p] = e * e;  // :294
                     }
@@ -779,7 +783,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
             } else if constexpr (RELAXED) {
                 if (wave < 3) {
                     // H22 = sum of c * c: the row re-reads one constant, so its sum is P * c * c
-                    double s = cid < 11 ? relaxed_row_f64(stream + (size_t)stream_of[cid] * PP, P, lr, row_s1)
+                    double s = cid < 11 ? relaxed_row_f64(stream + (size_t)stream_of[cid] * PS, P, lr, row_s1)
                                         : (double)P * cd * cd;
                     if (lr == 15) acc[cid] = s;
                 } else {
