@@ -27,6 +27,16 @@ struct DevLevel {
     float fcols_m1, frows_m1; // (float)(cols-1), (float)(rows-1) -- the clamp target
 };
 
+// A feature handed over mid-flight by a throughput kernel to the latency kernel (k_track_resume): everything the
+// Gauss-Newton loop carries from one iteration to the next (src/patch_match.cpp:186-194, :332-340).  The level's
+// constants (pt, the img1 samples) are recomputed by the resuming kernel: they depend on the inputs only.
+struct SuspState {
+    int level;     // pyramid level being iterated
+    int iter;      // index of the next iteration at that level (>= 1: at least one iteration ran there)
+    float dx, dy, dg, db, lastCost;
+    int iters;     // iterations executed so far, all levels (diagnostic output)
+};
+
 struct TrackArgs {
     DevLevel l1[kMaxLevels], l2[kMaxLevels];
     float scales[kMaxLevels];
@@ -45,6 +55,13 @@ struct TrackArgs {
     int *iters;
     unsigned long long *dbg;  // diagnostic builds only (PAGK_STAMPS)
     float *ws;                // k_track_quad: per-wave scratch for the iteration-invariant img1 samples
+    // continuation (large launches): a feature that has executed `iter_budget` iterations without finishing is
+    // suspended -- its state goes to susp_state[feature], its index is appended to susp_list -- and finished by
+    // k_track_resume.  iter_budget = 0: never suspend.
+    int iter_budget;
+    int *susp_count;
+    int *susp_list;
+    SuspState *susp_state;
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

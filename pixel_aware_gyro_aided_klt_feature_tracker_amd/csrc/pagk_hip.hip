@@ -49,6 +49,10 @@ struct pagk_ctx {
     FeatBuf score;  // scratch of the host-buffer geometry scoring path
     void *quad_ws = nullptr;  // k_track_quad: iteration-invariant img1 samples, 4 * NCH * 64 floats per wave
     size_t quad_ws_bytes = 0;
+    void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
+    size_t susp_bytes = 0;
+    int quad_budget = 0;      // PAGK_QUAD_BUDGET: iterations a feature may run in the throughput kernel before it is
+                              // handed to k_track_resume; 0 (default): no hand-over (profiles/r02_ab_runs.md)
     // hipGraph capture of the per-frame work (pagk_graph_*): while capturing, nothing may allocate and the
     // timing events are left out (an event recorded into a graph cannot be read back)
     bool capturing = false;
@@ -333,6 +337,28 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 ctx->quad_ws_bytes = need;
             }
             a.ws = static_cast<float *>(ctx->quad_ws);
+            // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
+            const bool handover = ctx->quad_budget > 0;
+            if (handover) {
+                const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
+                if (need_s > ctx->susp_bytes) {
+                    if (ctx->capturing) {
+                        snprintf(ctx->err, sizeof(ctx->err), "the continuation buffers would have to be (re)allocated during graph capture");
+                        return PAGK_E_ARG;
+                    }
+                    if (ctx->susp) HIPCHK(ctx, hipFree(ctx->susp));
+                    ctx->susp = nullptr;
+                    ctx->susp_bytes = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->susp, need_s));
+                    ctx->susp_bytes = need_s;
+                }
+                uint8_t *sb = static_cast<uint8_t *>(ctx->susp);
+                a.iter_budget = ctx->quad_budget;
+                a.susp_count = reinterpret_cast<int *>(sb);
+                a.susp_list = reinterpret_cast<int *>(sb + 256);
+                a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
+                HIPCHK(ctx, hipMemsetAsync(a.susp_count, 0, 4, ctx->stream));
+            }
             auto launch = [&](auto kern) -> hipError_t {
                 hipLaunchKernelGGL(kern, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, a);
                 return hipGetLastError();
@@ -342,6 +368,19 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_quad<4>);   // P = 225
             else if (a.half == 10) e = launch(k_track_quad<7>);  // P = 441
             HIPCHK(ctx, e);
+            if (handover) {
+                // second pass: the latency kernel finishes the suspended features (a fixed grid walks the list)
+                const size_t lds = track_block_lds_bytes(a.half);
+                const int grid = n < 1024 ? n : 1024;
+                auto resume = [&](auto kern) -> hipError_t {
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
+                    return hipGetLastError();
+                };
+                if (a.half == 5) e = resume(k_track_resume<1, 25>);
+                else if (a.half == 7) e = resume(k_track_resume<1, 1>);
+                else e = resume(k_track_resume<2, 25>);
+                HIPCHK(ctx, e);
+            }
         } else if (use_wave) {
             // one wavefront per feature (pagk_wave_kernel.h)
             const size_t lds = track_wave_lds_bytes(a.half);
@@ -617,6 +656,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
+    if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
     for (int k = 0; k < 2; k++) {
         if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
             pagk_destroy(ctx);
@@ -643,6 +683,7 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->feat.host) (void)hipHostFree(ctx->feat.host);
     if (ctx->score.block) (void)hipFree(ctx->score.block);
     if (ctx->quad_ws) (void)hipFree(ctx->quad_ws);
+    if (ctx->susp) (void)hipFree(ctx->susp);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
         if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);

@@ -500,8 +500,9 @@ __device__ __forceinline__ float relaxed_row_f32(const float *arr, int P, int lr
     return s;
 }
 
+// `i`: the feature; `resume`: nullptr, or the state a throughput kernel suspended the feature in (k_track_resume).
 template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
-__device__ __forceinline__ void track_block_body(const TrackArgs &a)
+__device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i, const SuspState *resume = nullptr)
 {
     static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
     static_assert(!(MFMA && RELAXED), "the relaxed-order experiment exists for the 4-wave kernel only");
@@ -509,7 +510,6 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
     constexpr int kStreams = MFMA ? 3 : 8;
     constexpr int kAcc = MFMA ? 24 : 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int i = blockIdx.x;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
@@ -605,7 +605,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #ifdef PAGK_STAMPS
     // diagnostic build only: cycles per phase, summed over iterations, written to a.dbg (a buffer
     // nothing else reads).  [0] level setup, [1] sampling, [2] chains, [3] solve, [4] update, [5] total
-    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_begin = __builtin_amdgcn_s_memtime(), t0, t1;
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 #define STAMP(k)                                  \
@@ -616,7 +616,8 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 #define STAMP(k)
 #endif
 
-    for (int level = a.n_levels - 1; level >= 0; level--) {
+    const int level_first = resume ? resume->level : a.n_levels - 1;
+    for (int level = level_first; level >= 0; level--) {
 #ifdef PAGK_STAMPS
         t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -634,6 +635,13 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
         float dx = nx - ptx, dy = ny - pty, dg = 0.0f, db = 0.0f;  // :186-191
         lastCost = 0.0f;                                            // :193
         succ = 1;                                                   // :194
+        int iter_first = 0;
+        if (resume && level == level_first) {  // pick the feature up where the throughput kernel left it
+            dx = resume->dx, dy = resume->dy, dg = resume->dg, db = resume->db;
+            lastCost = resume->lastCost;
+            iters = resume->iters;
+            iter_first = resume->iter;
+        }
 
         // img1 samples are iteration-invariant: once per level (bit-identical to :253, :263)
         const float cneg = -sample<true>(L1, ptx, pty);
@@ -658,7 +666,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
         }
 
         STAMP(0)
-        for (int iter = 0; iter < a.iterations; iter++) {  // :215
+        for (int iter = iter_first; iter < a.iterations; iter++) {  // :215
             iters++;
             // ---- 1. sampling ------------------------------------------------------------------
             const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
@@ -680,6 +688,11 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
                     const int r = r0 + u < NR ? r0 + u : NR - 1;
                     float X = bx + wx[r], Y = by + wy[r];
                     taps[u] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+#ifdef PAGK_STAMPS
+                    if (r0 == 0 && u == 0) {
+                        STAMP(13)  // first round's coordinates computed and gathers issued
+                    }
+#endif
                 }
 #ifdef PAGK_STAMPS
                 if (r0 == 0) {
@@ -855,6 +868,10 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
             lastCost = cost;  // :339
             succ = 1;
             if (unorm < 1e-2) break;  // :343
+#ifdef PAGK_STAMPS
+            asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dg), "+v"(db));
+            STAMP(12)  // update read back, applied, termination tests
+#endif
         }
         p2x = ptx + dx;  // :348
         p2y = pty + dy;
@@ -921,12 +938,16 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
     if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, ncc, iters);
 #ifdef PAGK_STAMPS
     if (tid == 0 && a.dbg) {
+        // resumed features: after the throughput kernel's per-wave records
+        unsigned long long *dbgp = a.dbg + (resume ? (size_t)16 * ((a.n + 3) / 4) : 0);
         st[5] = __builtin_amdgcn_s_memtime() - t_begin;
-        for (int k = 0; k < 6; k++) a.dbg[(size_t)i * 16 + k] = st[k];
-        a.dbg[(size_t)i * 16 + 6] = (unsigned long long)iters;
-        a.dbg[(size_t)i * 16 + 7] = rt_begin;  // 100 MHz wall clock, common to all XCDs (s_memtime is per XCD)
-        for (int k = 8; k < 11; k++) a.dbg[(size_t)i * 16 + k] = st[k];
-        a.dbg[(size_t)i * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 6; k++) dbgp[(size_t)i * 16 + k] = st[k];
+        dbgp[(size_t)i * 16 + 6] = (unsigned long long)iters;
+        dbgp[(size_t)i * 16 + 7] = rt_begin;  // 100 MHz wall clock, common to all XCDs (s_memtime is per XCD)
+        for (int k = 8; k < 11; k++) dbgp[(size_t)i * 16 + k] = st[k];
+        dbgp[(size_t)i * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+        dbgp[(size_t)i * 16 + 12] = st[12];
+        dbgp[(size_t)i * 16 + 13] = st[13];
     }
 #endif
 #undef STAMP
@@ -938,7 +959,22 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a)
 template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
 __global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
 {
-    track_block_body<NR, TAIL, WAVES, MFMA, RELAXED>(a);
+    track_block_body<NR, TAIL, WAVES, MFMA, RELAXED>(a, (int)blockIdx.x);
+}
+
+// The latency kernel as the second pass of a large launch: finishes the features a throughput kernel suspended
+// (TrackArgs::iter_budget).  A fixed grid walks the list; *susp_count is read on the device, so the launch is the
+// same whatever the count (graph-capturable).
+template <int NR, int TAIL>
+__global__ void __launch_bounds__(256, 4) k_track_resume(TrackArgs a)
+{
+    const int count = *a.susp_count;
+    for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
+        const int i = a.susp_list[b];
+        const SuspState st = a.susp_state[i];
+        track_block_body<NR, TAIL, 4, false, false>(a, i, &st);
+        __syncthreads();  // LDS is reused by the next feature
+    }
 }
 
 // The 4-wave kernel with the NEXT frame's pyramid built by trailing workgroups of the same launch: blocks
@@ -952,7 +988,7 @@ __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs
         pyr_block(pa, (int)blockIdx.x - a.n, (int)threadIdx.x);
         return;
     }
-    track_block_body<NR, TAIL, 4, false, false>(a);
+    track_block_body<NR, TAIL, 4, false, false>(a, (int)blockIdx.x);
 }
 
 }  // namespace pagk

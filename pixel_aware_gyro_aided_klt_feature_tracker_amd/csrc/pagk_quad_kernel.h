@@ -90,6 +90,21 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 
     int succ = 1, iters = 0;
     float lastCost = 0.0f;
+    bool susp = false;  // this row's feature was handed to k_track_resume (TrackArgs::iter_budget)
+#ifdef PAGK_STAMPS
+    // diagnostic build only: cycles per phase of this wave -> a.dbg[16 * wave + k]: [0] level setup, [1] sampling,
+    // [2] MFMA chain, [3] cost chain, [4] solve + update, [5] total, [6] wave-iterations
+    unsigned long long qst[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long qt0 = __builtin_amdgcn_s_memtime(), qt1;
+    const unsigned long long qbegin = qt0;
+    const unsigned long long qreal0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole device
+#define QSTAMP(k)                          \
+    qt1 = __builtin_amdgcn_s_memtime();    \
+    qst[k] += qt1 - qt0;                   \
+    qt0 = qt1;
+#else
+#define QSTAMP(k)
+#endif
 
     for (int level = a.n_levels - 1; level >= 0; level--) {
         const DevLevel &L1 = a.l1[level];
@@ -106,7 +121,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         float dx = nx - ptx, dy = ny - pty, dg = 0.0f, db = 0.0f;  // :186-191
         lastCost = 0.0f;                                            // :193
         succ = 1;                                                   // :194
-        bool act = live;
+        bool act = live && !susp;
 
         // img1 samples are iteration-invariant (bit-identical to :253, :263): once per level, for all four features
         const float cneg = -sample<true>(L1, ptx, pty);
@@ -125,8 +140,24 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         __syncthreads();  // the previous level's readers of cconst are done
         S.cconst[row][lr] = cd;
         __syncthreads();
+        QSTAMP(0)
 
         for (int iter = 0; iter < a.iterations; iter++) {  // :215
+            // Continuation: a feature that has used up the launch's iteration budget without finishing leaves this
+            // wave here, between two iterations -- everything the loop carries (:186-194, :332-340) goes to
+            // susp_state -- and is finished by k_track_resume, the latency kernel.  The slowest features (a handful
+            // run 3-5x the mean iteration count) would otherwise keep a whole throughput wave, and the launch, waiting.
+            if (a.iter_budget > 0 && act && iters >= a.iter_budget && iter > 0) {
+                if (lr == 0) {
+                    SuspState ss;
+                    ss.level = level, ss.iter = iter, ss.dx = dx, ss.dy = dy, ss.dg = dg, ss.db = db;
+                    ss.lastCost = lastCost, ss.iters = iters;
+                    a.susp_state[fi] = ss;
+                    a.susp_list[atomicAdd(a.susp_count, 1)] = fi;
+                }
+                act = false;
+                susp = true;
+            }
             const unsigned long long actm = __ballot(act);
             if (actm == 0ull) break;
             if (act) iters++;
@@ -145,8 +176,17 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 patch_xy(c, x, y);
                 const bool valid = 64 * c + lane < P;
                 // the active features of the wave, in order (wave-uniform); the gathers of feature k+1 are issued
-                // before feature k's are consumed, so that a round's latency hides behind the previous round's math
-                auto issue = [&](int f, FiveTaps &tp, float &s1v) {
+                // before feature k's are consumed, so that a round's latency hides behind the previous round's math.
+                // Two named tap sets alternate and every consume sits on its own control path: a copy "cur = nxt" or a
+                // consume shared by the paths with / without a following issue would each make the compiler wait
+                // for ALL outstanding loads (s_waitcnt vmcnt(0)) -- the pipelining would exist in the source only.
+                // the img1 samples of the chunk come first, all four features: loads return in order, so these are never
+                // waited for together with taps in flight (a register holding a pending load, paired by the allocator
+                // with a live weight in a packed operand, costs a wait for everything issued before it)
+                float s1q[4];
+#pragma unroll
+                for (int f = 0; f < 4; f++) s1q[f] = ws[(f * NCH + c) * 64];
+                auto issue = [&](int f, FiveTaps &tp) {
                     const int src = 16 * f;
                     float wx = x, wy = y;
                     if (a.use_affine) {  // :203-204
@@ -155,45 +195,57 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     }
                     const float X = rl(bx, src) + wx, Y = rl(by, src) + wy;
                     tp = ((intm >> src) & 1ull) ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
-                    s1v = ws[(f * NCH + c) * 64];
                 };
-                int f = __builtin_ctzll(actm) >> 4;            // first active feature
-                unsigned long long rest = actm & ~(0xffffull << (16 * f));
-                FiveTaps cur;
-                float s1cur;
-                issue(f, cur, s1cur);
-                while (true) {
-                    const int fn = rest ? (__builtin_ctzll(rest) >> 4) : -1;
-                    FiveTaps nxt;
-                    float s1nxt = 0.0f;
-#ifndef PAGK_QUAD_NO_PIPE
-                    if (fn >= 0) {
-                        rest &= ~(0xffffull << (16 * fn));
-                        issue(fn, nxt, s1nxt);
-                    }
-#endif
+                auto consume = [&](int f, const FiveTaps &tp) {
                     const int src = 16 * f;
-                    const Five s = sample5_finish(cur);
-#ifdef PAGK_QUAD_NO_PIPE
-                    if (fn >= 0) {
-                        rest &= ~(0xffffull << (16 * fn));
-                        issue(fn, nxt, s1nxt);
-                    }
-#endif
-                    const float e = s.c + rl(db, src) - rl(gain, src) * s1cur;  // :252-253
-                    const float Ix = 0.5f * (s.xp - s.xm);                       // :259-260
-                    const float Iy = 0.5f * (s.yp - s.ym);                       // :261-262
+                    const float s1v = f == 0 ? s1q[0] : f == 1 ? s1q[1] : f == 2 ? s1q[2] : s1q[3];
+                    const Five s = sample5_finish(tp);
+                    const float e = s.c + rl(db, src) - rl(gain, src) * s1v;  // :252-253
+                    const float Ix = 0.5f * (s.xp - s.xm);                     // :259-260
+                    const float Iy = 0.5f * (s.yp - s.ym);                     // :261-262
                     S.chunk[0][f][lane] = (double)Ix;
                     S.chunk[1][f][lane] = (double)Iy;
                     S.chunk[2][f][lane] = -(double)e;
                     S.sq[f * 129 + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
-                    if (fn < 0) break;
-                    f = fn;
-                    cur = nxt;
-                    s1cur = s1nxt;
+                };
+                auto first_of = [](unsigned long long m) { return (int)(__builtin_ctzll(m) >> 4); };
+                auto without = [](unsigned long long m, int f) { return m & ~(0xffffull << (16 * f)); };
+                int fa = first_of(actm), fb = 0;
+                unsigned long long rest = without(actm, fa);
+                FiveTaps ta, tb;
+                bool last_in_a = true;
+                issue(fa, ta);
+#pragma nounroll
+                while (rest) {  // a next feature exists: its gathers go out before the current taps are consumed
+                    fb = first_of(rest);
+                    rest = without(rest, fb);
+                    issue(fb, tb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(fa, ta);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!rest) {
+                        last_in_a = false;
+                        break;
+                    }
+                    fa = first_of(rest);
+                    rest = without(rest, fa);
+                    issue(fa, ta);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(fb, tb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the last feature of the chunk: nothing is in flight behind it (kept apart from the consumes in the
+                // loop: a shared copy would have to wait as if nothing were in flight there either)
+                if (last_in_a) {
+                    asm volatile("; last taps: set a");
+                    consume(fa, ta);
+                } else {
+                    asm volatile("; last taps: set b");
+                    consume(fb, tb);
                 }
                 if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
+                QSTAMP(1)
                 // ---- H, b: one MFMA per four pixels, all four features ---------------------------------
                 {
                     const int left = P - 64 * c;                   // valid pixels from this chunk on
@@ -221,9 +273,14 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                         d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
                     }
                 }
+#ifdef PAGK_STAMPS
+                asm volatile("" : "+v"(d));
+                QSTAMP(2)
+#endif
                 // ---- cost: ordered f32 sum, row q = feature q ----------------------------------------
                 carry = chain_rows_f32<1>(sq_addr, 128u, 2);
                 __syncthreads();  // the chunk has been read before the next one is written
+                QSTAMP(3)
             }
             // ---- solve (:302-319): D(q, i, j) sits in lane 16 i + 4 q + j; every lane of row q solves feature q
             S.acc[mq][mk * 4 + mi] = d;
@@ -261,11 +318,25 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     if (unorm < 1e-2) act = false;  // :343
                 }
             }
+#ifdef PAGK_STAMPS
+            asm volatile("" : "+v"(dx), "+v"(dy));
+            qst[6]++;
+            QSTAMP(4)
+#endif
         }
         p2x = ptx + dx;  // :348
         p2y = pty + dy;
     }
-    if (lr == 0 && raw < a.n) {
+#ifdef PAGK_STAMPS
+    if (lane == 0 && a.dbg) {
+        qst[5] = __builtin_amdgcn_s_memtime() - qbegin;
+        for (int k = 0; k < 7; k++) a.dbg[(size_t)blockIdx.x * 16 + k] = qst[k];
+        a.dbg[(size_t)blockIdx.x * 16 + 7] = qreal0;
+        a.dbg[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#undef QSTAMP
+    if (lr == 0 && raw < a.n && !susp) {
         if (live)
             write_outputs(a, fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)
         else

@@ -107,6 +107,23 @@ def test_quad_kernel_on_baseline_configs(ctx, idx, n):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
+@pytest.mark.parametrize("budget", [0, 1, 3, 7, 20])
+def test_quad_kernel_continuation(monkeypatch, budget):
+    # the throughput kernel hands features that have run `budget` iterations to k_track_resume (the 4-wave body picks
+    # the Gauss-Newton loop up at the same level and iteration): same bits wherever the hand-over happens; 0 = never
+    monkeypatch.setenv("PAGK_QUAD_BUDGET", str(budget))
+    c = capi.Context(0)
+    try:
+        for idx, n, h in ((1, 1003, 10), (3, 3000, 10), (1, 600, 5), (1, 600, 7)):
+            w = synth.config(idx, n=n) if h == 10 else synth.make_workload(
+                f"cont-h{h}", 640, 480, n, seed=0x5EED0200 + h, half_patch=h, iterations=30, pyramids=3, camera=synth.D435I)
+            got, ref = run_both(c, params_for(w), w, kernel=5)
+            assert_parity(got, ref, w.n, exact=True, what=f"{w.name} budget {budget}")
+            assert c.last_variant() == 5
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("idx,n", [(0, 500), (1, 1000), (2, 2000), (3, 3000)])
 def test_baseline_configs_against_oracle(ctx, idx, n):
     # BASELINE.json configs (synthetic stand-ins); 21x21 patch, 30 iterations

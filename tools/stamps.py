@@ -27,13 +27,13 @@ it = d[:, 6]
 names = ["level setup", "sampling", "chains", "solve", "(unused)", "total"]
 print(f"kernel {trk*1e3:.1f} us (stamped build), mean iters {it.mean():.2f}")
 for k in (0, 1, 2, 3, 5):
-    val = d[:, k] + (d[:, 8] + d[:, 9] + d[:, 10] if k == 1 else 0)
+    val = d[:, k] + (d[:, 8] + d[:, 9] + d[:, 10] + d[:, 12] + d[:, 13] if k == 1 else 0)
     per_it = val / (it if k in (1, 2, 3) else 1)
     print(f"  {names[k]:12s}: mean {val.mean():9.0f} cyc/feature ({100*val.sum()/d[:, 5].sum():5.1f}%)"
           + (f", {per_it.mean():7.0f} cyc/iteration" if k in (1, 2, 3) else ""))
 # the sampling phase in pieces (workgroup thread 0's wave): [8] coordinates + gathers issued, [9] gathers returned,
 # [10] interpolation + products + LDS stores, [1] the rest = waiting at the barrier for the other waves
-for k, name in ((8, "  coords + issue"), (9, "  gather wait"), (10, "  math + stores"), (1, "  barrier wait")):
+for k, name in ((12, "  update/tests"), (13, "  round 0 coords+issue"), (8, "  round 1 coords+issue"), (9, "  gather wait"), (10, "  math + stores"), (1, "  barrier wait")):
     print(f"  {name:14s}: {(d[:, k] / it).mean():7.0f} cyc/iteration")
 # schedule of the launch from the 100 MHz wall clock (s_memrealtime): start / end of every workgroup, in us
 rb, re_ = d[:, 7], d[:, 11]
