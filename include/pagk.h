@@ -177,7 +177,9 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  *     given up (strided partial sums + tree instead of the 441-step ordered chains).  Not parity-exact:
  *     it exists to measure what the ordered accumulation costs.
  * 5 = four features per wavefront (block q of the f64 MFMA, row q of the cost chain and lane = feature solve shared
- *     by four features): the highest-throughput variant for very large launches; bit-identical like 0-3. */
+ *     by four features): a throughput variant for very large launches; bit-identical like 0-3.
+ * 6 = 5 with the four rows of a wave independent (each row runs its own feature at its own level and takes the next
+ *     feature from a work queue when it is done; a resident grid): bit-identical like 0-3. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 /* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
  * -1 before the first launch. */

@@ -27,6 +27,11 @@ struct DevLevel {
     float fcols_m1, frows_m1; // (float)(cols-1), (float)(rows-1) -- the clamp target
 };
 
+// Device-scope loads / stores that bypass the per-CU vector cache: the hand-over list is written by one kernel and read
+// by another one running at the same time.
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // A feature handed over mid-flight by a throughput kernel to the latency kernel (k_track_resume): everything the
 // Gauss-Newton loop carries from one iteration to the next (src/patch_match.cpp:186-194, :332-340).  The level's
 // constants (pt, the img1 samples) are recomputed by the resuming kernel: they depend on the inputs only.
@@ -59,9 +64,13 @@ struct TrackArgs {
     // suspended -- its state goes to susp_state[feature], its index is appended to susp_list -- and finished by
     // k_track_resume.  iter_budget = 0: never suspend.
     int iter_budget;
-    int *susp_count;
-    int *susp_list;
+    int *susp_count;   // [0] entries published, [1] tickets taken by the finisher, [2] throughput waves that have ended
+    int *susp_list;    // entry k: 0 = not (yet) published, feature + 1 = waiting, -(feature + 1) = finished
     SuspState *susp_state;
+    int susp_waves;    // waves of the throughput launch (what susp_count[2] reaches)
+    int susp_polls;    // how often a finisher workgroup looks for its entry before it gives up (bounded: never a hang)
+    // k_track_rows: the next feature index to hand out (zeroed before every launch)
+    int *queue;
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

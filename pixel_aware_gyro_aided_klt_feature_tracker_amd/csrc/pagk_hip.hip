@@ -49,8 +49,15 @@ struct pagk_ctx {
     FeatBuf score;  // scratch of the host-buffer geometry scoring path
     void *quad_ws = nullptr;  // k_track_quad: iteration-invariant img1 samples, 4 * NCH * 64 floats per wave
     size_t quad_ws_bytes = 0;
+    void *queue = nullptr;    // k_track_rows: the work-queue counter (256 B)
+    int rows_capacity[3] = {0, 0, 0};  // resident waves of k_track_rows<2 / 4 / 7> on this device (occupancy x CUs)
+    int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
     size_t susp_bytes = 0;
+    hipStream_t aux_stream = nullptr;  // the live finisher's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int finisher_wgs = 48;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
+    int finisher_polls = 4000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look)
     int quad_budget = 0;      // PAGK_QUAD_BUDGET: iterations a feature may run in the throughput kernel before it is
                               // handed to k_track_resume; 0 (default): no hand-over (profiles/r02_ab_runs.md)
     // hipGraph capture of the per-frame work (pagk_graph_*): while capturing, nothing may allocate and the
@@ -316,12 +323,53 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         // by default, when the launch has more features than can be resident at once
         const bool mfma_ok = a.half == 5 || a.half == 7 || a.half == 10;
         // four features per wave: no NCC epilogue of its own (calc_ncc launches run the one-wave-per-feature variant)
-        const bool use_quad = mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->quad_min_features));
-        const bool use_wave = !use_quad && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
+        // ... and with the four rows of a wave independent + a work queue (pagk_rows_kernel.h)
+        const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
+        const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n >= ctx->quad_min_features));
+        const bool use_wave = !use_quad && !use_rows && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
         const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
-        ctx->last_variant = ctx->kernel == 1 ? 1 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
+        ctx->last_variant = ctx->kernel == 1 ? 1 : use_rows ? 6 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+        } else if (use_rows) {
+            const int nch = (Pm + 63) / 64;
+            const int slot = a.half == 5 ? 0 : (a.half == 7 ? 1 : 2);
+            if (ctx->rows_capacity[slot] == 0) {
+                int per_cu = 0, cus = 0;
+                hipError_t oe = a.half == 5   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_rows<2>, 64, 0)
+                                : a.half == 7 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_rows<4>, 64, 0)
+                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_rows<7>, 64, 0);
+                HIPCHK(ctx, oe);
+                HIPCHK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+                ctx->rows_capacity[slot] = per_cu * cus > 0 ? per_cu * cus : 1024;
+            }
+            // a resident grid: every wave starts at once, rows pull the features past 4 * grid from the queue
+            int waves = (n + 3) / 4 < ctx->rows_capacity[slot] ? (n + 3) / 4 : ctx->rows_capacity[slot];
+            if (ctx->rows_waves_cap > 0 && waves > ctx->rows_waves_cap) waves = ctx->rows_waves_cap;
+            const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
+            if (need > ctx->quad_ws_bytes) {
+                if (ctx->capturing) {
+                    snprintf(ctx->err, sizeof(ctx->err), "the row kernel's workspace would have to be (re)allocated during graph capture");
+                    return PAGK_E_ARG;
+                }
+                if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
+                ctx->quad_ws = nullptr;
+                ctx->quad_ws_bytes = 0;
+                HIPCHK(ctx, hipMalloc(&ctx->quad_ws, need));
+                ctx->quad_ws_bytes = need;
+            }
+            a.ws = static_cast<float *>(ctx->quad_ws);
+            a.queue = static_cast<int *>(ctx->queue);
+            HIPCHK(ctx, hipMemsetAsync(a.queue, 0, 4, ctx->stream));
+            auto launch = [&](auto kern) -> hipError_t {
+                hipLaunchKernelGGL(kern, dim3(waves), dim3(64), 0, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e = hipErrorInvalidValue;
+            if (a.half == 5) e = launch(k_track_rows<2>);
+            else if (a.half == 7) e = launch(k_track_rows<4>);
+            else if (a.half == 10) e = launch(k_track_rows<7>);
+            HIPCHK(ctx, e);
         } else if (use_quad) {
             const int nch = (Pm + 63) / 64;
             const size_t need = (size_t)((n + 3) / 4) * 4 * nch * 64 * sizeof(float);
@@ -357,7 +405,16 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_count = reinterpret_cast<int *>(sb);
                 a.susp_list = reinterpret_cast<int *>(sb + 256);
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
-                HIPCHK(ctx, hipMemsetAsync(a.susp_count, 0, 4, ctx->stream));
+                a.susp_waves = (n + 3) / 4;
+                a.susp_polls = ctx->finisher_polls;
+                HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
+            }
+            // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (not inside a
+            // graph capture: there the sweep alone finishes the suspended features)
+            const bool live = handover && ctx->finisher_wgs > 0 && !ctx->capturing && ctx->aux_stream;
+            if (live) {
+                HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
             }
             auto launch = [&](auto kern) -> hipError_t {
                 hipLaunchKernelGGL(kern, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, a);
@@ -368,10 +425,23 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_quad<4>);   // P = 225
             else if (a.half == 10) e = launch(k_track_quad<7>);  // P = 441
             HIPCHK(ctx, e);
-            if (handover) {
-                // second pass: the latency kernel finishes the suspended features (a fixed grid walks the list)
+            if (live) {
                 const size_t lds = track_block_lds_bytes(a.half);
-                const int grid = n < 1024 ? n : 1024;
+                auto finisher = [&](auto kern) -> hipError_t {
+                    hipLaunchKernelGGL(kern, dim3(ctx->finisher_wgs), dim3(kBlock), lds, ctx->aux_stream, a);
+                    return hipGetLastError();
+                };
+                if (a.half == 5) e = finisher(k_track_resume_live<1, 25>);
+                else if (a.half == 7) e = finisher(k_track_resume_live<1, 1>);
+                else e = finisher(k_track_resume_live<2, 25>);
+                HIPCHK(ctx, e);
+                HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            }
+            if (handover) {
+                // the sweep: the latency kernel finishes what is still waiting in the list (a fixed grid walks it)
+                const size_t lds = track_block_lds_bytes(a.half);
+                const int grid = live ? 64 : (n < 1024 ? n : 1024);
                 auto resume = [&](auto kern) -> hipError_t {
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
                     return hipGetLastError();
@@ -652,11 +722,24 @@ int pagk_create(pagk_ctx **out, int device)
         return PAGK_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipMalloc(&ctx->queue, 256) != hipSuccess) {
+        pagk_destroy(ctx);
+        return PAGK_E_NOMEM;
+    }
     ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
+    if (getenv("PAGK_ROWS_WAVES")) ctx->rows_waves_cap = atoi(getenv("PAGK_ROWS_WAVES"));
+    if (getenv("PAGK_FINISHER_WGS")) ctx->finisher_wgs = atoi(getenv("PAGK_FINISHER_WGS"));
+    if (getenv("PAGK_FINISHER_POLLS")) ctx->finisher_polls = atoi(getenv("PAGK_FINISHER_POLLS"));
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        pagk_destroy(ctx);
+        return PAGK_E_HIP;
+    }
     for (int k = 0; k < 2; k++) {
         if (hipEventCreate(&ctx->ev_trk[k]) != hipSuccess || hipEventCreate(&ctx->ev_pyr[k]) != hipSuccess) {
             pagk_destroy(ctx);
@@ -672,6 +755,12 @@ void pagk_destroy(pagk_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < pagk_ctx::kGraphs; k++)
         if (ctx->graph_execs[k]) {
             (void)hipGraphExecDestroy(ctx->graph_execs[k]);
@@ -684,6 +773,7 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->score.block) (void)hipFree(ctx->score.block);
     if (ctx->quad_ws) (void)hipFree(ctx->quad_ws);
     if (ctx->susp) (void)hipFree(ctx->susp);
+    if (ctx->queue) (void)hipFree(ctx->queue);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
         if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);
@@ -701,7 +791,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
 
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
-    if (!ctx || which < 0 || which > 5) return PAGK_E_ARG;
+    if (!ctx || which < 0 || which > 6) return PAGK_E_ARG;
     ctx->kernel = which;
     return PAGK_OK;
 }

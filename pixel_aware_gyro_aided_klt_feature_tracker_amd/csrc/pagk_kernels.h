@@ -965,13 +965,67 @@ __global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
 // The latency kernel as the second pass of a large launch: finishes the features a throughput kernel suspended
 // (TrackArgs::iter_budget).  A fixed grid walks the list; *susp_count is read on the device, so the launch is the
 // same whatever the count (graph-capturable).
+__device__ __forceinline__ SuspState load_susp_state(const TrackArgs &a, int i)
+{
+    const int *p = reinterpret_cast<const int *>(&a.susp_state[i]);
+    SuspState st;
+    st.level = ld_agent(p + 0), st.iter = ld_agent(p + 1);
+    st.dx = __int_as_float(ld_agent(p + 2)), st.dy = __int_as_float(ld_agent(p + 3));
+    st.dg = __int_as_float(ld_agent(p + 4)), st.db = __int_as_float(ld_agent(p + 5));
+    st.lastCost = __int_as_float(ld_agent(p + 6)), st.iters = ld_agent(p + 7);
+    return st;
+}
+
+// The finisher that runs BESIDE the throughput kernel (another stream): each workgroup draws a ticket k and waits for
+// list entry k to be published, finishes that feature with the 4-wave body and draws again.  It ends when the
+// throughput launch has ended (susp_count[2] == susp_waves) and its entry was not published -- or after susp_polls
+// looks, whatever happened: a bounded wait, k_track_resume sweeps up behind it.
+template <int NR, int TAIL>
+__global__ void __launch_bounds__(256, 4) k_track_resume_live(TrackArgs a)
+{
+    __shared__ int s_entry;
+    const int tid = threadIdx.x;
+    int polls = 0;
+    for (;;) {
+        if (tid == 0) {
+            int entry = 0;
+            const int ticket = atomicAdd(a.susp_count + 1, 1);
+            if (ticket < a.n) {
+                for (;;) {
+                    entry = __hip_atomic_load(a.susp_list + ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (entry != 0) break;
+                    if (ld_agent(a.susp_count + 2) >= a.susp_waves) {  // the producers are gone: a last look
+                        entry = __hip_atomic_load(a.susp_list + ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    if (++polls > a.susp_polls) break;
+                    __builtin_amdgcn_s_sleep(64);
+                }
+            }
+            s_entry = entry > 0 ? ticket + 1 : 0;
+        }
+        __syncthreads();
+        const int slot = s_entry - 1;
+        if (slot < 0) return;  // (uniform)
+        const int i = ld_agent(a.susp_list + slot) - 1;
+        const SuspState st = load_susp_state(a, i);
+        track_block_body<NR, TAIL, 4, false, false>(a, i, &st);
+        __syncthreads();  // LDS and s_entry are reused
+        if (tid == 0) st_agent(a.susp_list + slot, -(i + 1));
+    }
+}
+
+// The sweep after both: every published entry that is still waiting (all of them when the live finisher is not used).
+// A fixed grid walks the list; the count is read on the device, so the launch is the same whatever it is.
 template <int NR, int TAIL>
 __global__ void __launch_bounds__(256, 4) k_track_resume(TrackArgs a)
 {
     const int count = *a.susp_count;
     for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
-        const int i = a.susp_list[b];
-        const SuspState st = a.susp_state[i];
+        const int entry = a.susp_list[b];
+        if (entry <= 0) continue;  // finished by the live finisher
+        const int i = entry - 1;
+        const SuspState st = load_susp_state(a, i);
         track_block_body<NR, TAIL, 4, false, false>(a, i, &st);
         __syncthreads();  // LDS is reused by the next feature
     }
@@ -995,5 +1049,6 @@ __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs
 
 #include "pagk_wave_kernel.h"
 #include "pagk_quad_kernel.h"
+#include "pagk_rows_kernel.h"
 #include "pagk_score_kernel.h"
 #include "pagk_neighbor_kernel.h"

@@ -33,14 +33,19 @@ __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p
                                               float lastCost, int level0_ran, float ncc, int iters);
 __device__ __forceinline__ uint32_t lds_off(const void *p);
 
+// 10000 bytes: eight 1280-byte LDS granules, 16 waves per CU (with the accumulators in a member of their own the
+// ninth granule cost two resident waves per CU).
 struct QuadLds {
     double chunk[3][4][66];  // X | Y | NE streams of the current chunk: [stream][feature][pixel]; the strides put the
-                             // three streams 64 B and the four features 16 B apart modulo the 256-B bank span
+                             // three streams 64 B and the four features 16 B apart modulo the 256-B bank span.
+                             // After the last chunk of an iteration its first 64 doubles hold D of the four blocks
+                             // (quad_acc) until the solve has read them.
     double cconst[4][34];    // 16 x c per feature (A operand of entry 2, B operand of entry 3), 16 B apart mod 256
     double ones[32];         // 16 x 1.0 (A operand of entry 3)
-    double acc[4][16];       // D of the four blocks after the last chunk
     float sq[4 * 129 + 64];  // per feature: carry, 64 squares; rows 129 floats apart (odd: rows 0/1 use disjoint banks)
 };
+
+__device__ __forceinline__ double (*quad_acc(QuadLds &S))[16] { return reinterpret_cast<double (*)[16]>(&S.chunk[0][0][0]); }
 
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
@@ -66,6 +71,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
     if (__ballot(live) == 0ull) {  // nothing to track in this wave (:173)
         if (lr == 0 && raw < a.n) write_outputs(a, fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
+        if (lane == 0 && a.iter_budget > 0) atomicAdd(a.susp_count + 2, 1);
         return;
     }
 
@@ -149,11 +155,15 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             // run 3-5x the mean iteration count) would otherwise keep a whole throughput wave, and the launch, waiting.
             if (a.iter_budget > 0 && act && iters >= a.iter_budget && iter > 0) {
                 if (lr == 0) {
-                    SuspState ss;
-                    ss.level = level, ss.iter = iter, ss.dx = dx, ss.dy = dy, ss.dg = dg, ss.db = db;
-                    ss.lastCost = lastCost, ss.iters = iters;
-                    a.susp_state[fi] = ss;
-                    a.susp_list[atomicAdd(a.susp_count, 1)] = fi;
+                    // state first, then the list entry that publishes it (the finisher runs concurrently)
+                    int *st = reinterpret_cast<int *>(&a.susp_state[fi]);
+                    st_agent(st + 0, level), st_agent(st + 1, iter);
+                    st_agent(st + 2, __float_as_int(dx)), st_agent(st + 3, __float_as_int(dy));
+                    st_agent(st + 4, __float_as_int(dg)), st_agent(st + 5, __float_as_int(db));
+                    st_agent(st + 6, __float_as_int(lastCost)), st_agent(st + 7, iters);
+                    __threadfence();
+                    const int slot = atomicAdd(a.susp_count, 1);
+                    __hip_atomic_store(a.susp_list + slot, fi + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 act = false;
                 susp = true;
@@ -175,6 +185,16 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 float x, y;
                 patch_xy(c, x, y);
                 const bool valid = 64 * c + lane < P;
+                auto issue = [&](int f, FiveTaps &tp) {
+                    const int src = 16 * f;
+                    float wx = x, wy = y;
+                    if (a.use_affine) {  // :203-204
+                        wx = rl(A00, src) * x + rl(A01, src) * y;
+                        wy = rl(A10, src) * x + rl(A11, src) * y;
+                    }
+                    const float X = rl(bx, src) + wx, Y = rl(by, src) + wy;
+                    tp = ((intm >> src) & 1ull) ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+                };
                 // the active features of the wave, in order (wave-uniform); the gathers of feature k+1 are issued
                 // before feature k's are consumed, so that a round's latency hides behind the previous round's math.
                 // Two named tap sets alternate and every consume sits on its own control path: a copy "cur = nxt" or a
@@ -186,16 +206,6 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 float s1q[4];
 #pragma unroll
                 for (int f = 0; f < 4; f++) s1q[f] = ws[(f * NCH + c) * 64];
-                auto issue = [&](int f, FiveTaps &tp) {
-                    const int src = 16 * f;
-                    float wx = x, wy = y;
-                    if (a.use_affine) {  // :203-204
-                        wx = rl(A00, src) * x + rl(A01, src) * y;
-                        wy = rl(A10, src) * x + rl(A11, src) * y;
-                    }
-                    const float X = rl(bx, src) + wx, Y = rl(by, src) + wy;
-                    tp = ((intm >> src) & 1ull) ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
-                };
                 auto consume = [&](int f, const FiveTaps &tp) {
                     const int src = 16 * f;
                     const float s1v = f == 0 ? s1q[0] : f == 1 ? s1q[1] : f == 2 ? s1q[2] : s1q[3];
@@ -283,11 +293,11 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 QSTAMP(3)
             }
             // ---- solve (:302-319): D(q, i, j) sits in lane 16 i + 4 q + j; every lane of row q solves feature q
-            S.acc[mq][mk * 4 + mi] = d;
+            quad_acc(S)[mq][mk * 4 + mi] = d;
             __syncthreads();
             double H[4][4], b[4], upd[4];
             {
-                const double *A = S.acc[row];
+                const double *A = quad_acc(S)[row];
                 H[0][0] = A[0], H[1][0] = A[4], H[1][1] = A[5];
                 H[2][0] = A[8], H[2][1] = A[9], H[2][2] = A[11];
                 H[3][0] = A[12], H[3][1] = A[13];
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             float cost = carry;
             if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
             const double unorm = llt4_solve_norm(H, b, upd);
-            __syncthreads();  // S.acc is rewritten by the next iteration
+            __syncthreads();  // the accumulators' LDS is the next iteration's first chunk
             // ---- update + termination (:322-344), per feature ------------------------------------------
             if (act) {
                 if (upd[0] != upd[0]) {  // :322
@@ -341,6 +351,10 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             write_outputs(a, fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)
         else
             write_outputs(a, fi, init[2 * fi], init[2 * fi + 1], 0, 0.0f, 0, 0.0f, 0);
+    }
+    if (a.iter_budget > 0) {  // this wave publishes nothing from here on (its entries are visible: fenced above)
+        __threadfence();
+        if (lane == 0) atomicAdd(a.susp_count + 2, 1);
     }
 }
 

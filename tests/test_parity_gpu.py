@@ -107,11 +107,59 @@ def test_quad_kernel_on_baseline_configs(ctx, idx, n):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
-@pytest.mark.parametrize("budget", [0, 1, 3, 7, 20])
-def test_quad_kernel_continuation(monkeypatch, budget):
-    # the throughput kernel hands features that have run `budget` iterations to k_track_resume (the 4-wave body picks
-    # the Gauss-Newton loop up at the same level and iteration): same bits wherever the hand-over happens; 0 = never
+@pytest.mark.parametrize("name", golden_cases())
+def test_rows_kernel_matches_golden_vectors(ctx, name):
+    # four independent rows per wave + work queue (pagk_rows_kernel.h)
+    params, inp, exp = load_golden(name)
+    ctx.set_kernel(6)
+    try:
+        got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                        inp["status_in"])
+    finally:
+        ctx.set_kernel(0)
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("idx,n", [(1, 1000), (1, 1001), (1, 1002), (1, 1003), (3, 6000)])
+def test_rows_kernel_on_baseline_configs(ctx, idx, n):
+    w = synth.config(idx, n=n)
+    got, ref = run_both(ctx, params_for(w), w, kernel=6)
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+    assert ctx.last_variant() == 6
+
+
+@pytest.mark.parametrize("waves", [1, 3, 64])
+def test_rows_kernel_work_queue(monkeypatch, waves):
+    # a grid of `waves` wavefronts: all but the first 4 * waves features reach their row through the queue, rows of a
+    # wave sit at different levels and iterations of different features -- same bits; features switched off on input
+    # (status_in = 0) are written and skipped by the row that draws them
+    monkeypatch.setenv("PAGK_ROWS_WAVES", str(waves))
+    c = capi.Context(0)
+    try:
+        for idx, n, h in ((1, 1003, 10), (3, 1500, 10), (1, 300, 5), (1, 300, 7)):
+            w = synth.config(idx, n=n) if h == 10 else synth.make_workload(
+                f"rows-h{h}", 640, 480, n, seed=0x5EED0300 + h, half_patch=h, iterations=30, pyramids=3, camera=synth.D435I)
+            w.status_in[::7] = 0
+            got, ref = run_both(c, params_for(w), w, kernel=6)
+            assert_parity(got, ref, w.n, exact=True, what=f"{w.name} on {waves} waves")
+            assert c.last_variant() == 6
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("budget,finisher", [(0, "live"), (1, "live"), (3, "live"), (7, "live"), (20, "live"),
+                                             (3, "sweep"), (20, "sweep"), (3, "impatient"), (12, "impatient")])
+def test_quad_kernel_continuation(monkeypatch, budget, finisher):
+    # the throughput kernel hands features that have run `budget` iterations to the latency kernel (the 4-wave body
+    # picks the Gauss-Newton loop up at the same level and iteration): same bits wherever the hand-over happens;
+    # 0 = never.  "live": the finisher runs beside the throughput kernel on the auxiliary stream; "sweep": only the
+    # pass after it; "impatient": a live finisher that gives up at its first look, so the sweep finds entries in
+    # every state (finished, waiting, published late).
     monkeypatch.setenv("PAGK_QUAD_BUDGET", str(budget))
+    if finisher == "sweep":
+        monkeypatch.setenv("PAGK_FINISHER_WGS", "0")
+    if finisher == "impatient":
+        monkeypatch.setenv("PAGK_FINISHER_POLLS", "0")
     c = capi.Context(0)
     try:
         for idx, n, h in ((1, 1003, 10), (3, 3000, 10), (1, 600, 5), (1, 600, 7)):

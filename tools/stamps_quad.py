@@ -13,7 +13,8 @@ nw = (w.n + 3) // 4
 dbg = torch.zeros((nw + w.n) * 16, dtype=torch.int64, device="cuda")
 os.environ["PAGK_DBG_PTR"] = str(dbg.data_ptr())
 ctx = capi.Context(0)
-ctx.set_kernel(5)
+kern = int(os.environ.get("PAGK_KERNEL", "5"))   # 5: k_track_quad, 6: k_track_rows (timeline only)
+ctx.set_kernel(kern)
 p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
 for _ in range(2):
     out = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
@@ -27,6 +28,8 @@ wi = d[:, 6]
 it = out["iters"][:w.n]
 print(f"cfg{cfg} n={w.n}: kernel {trk*1e3:.1f} us (stamped build), {len(d)} waves, wave-iterations mean {wi.mean():.1f} "
       f"(features: mean {it[w.status_in > 0].mean():.1f} iterations)")
+if kern == 6:
+    d[:, 5] = 1
 names = ["level setup", "sampling", "MFMA chain", "cost chain", "solve+update", "total"]
 for k in range(6):
     per = d[:, k] / (wi if k in (1, 2, 3, 4) else 1)
