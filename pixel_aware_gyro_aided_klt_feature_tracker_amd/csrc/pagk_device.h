@@ -67,6 +67,7 @@ struct TrackArgs {
     int *susp_count;   // [0] entries published, [1] tickets taken by the finisher, [2] throughput waves that have ended
     int *susp_list;    // entry k: 0 = not (yet) published, feature + 1 = waiting, -(feature + 1) = finished
     SuspState *susp_state;
+    int susp_lone;     // suspend a feature only when no other row of its wave is iterating
     int susp_waves;    // waves of the throughput launch (what susp_count[2] reaches)
     int susp_polls;    // how often a finisher workgroup looks for its entry before it gives up (bounded: never a hang)
     // k_track_rows: the next feature index to hand out (zeroed before every launch)

@@ -56,7 +56,8 @@ struct pagk_ctx {
     size_t susp_bytes = 0;
     hipStream_t aux_stream = nullptr;  // the live finisher's stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int finisher_wgs = 48;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
+    int susp_lone = 1;        // PAGK_SUSPEND_LONE=0: hand every feature over at the budget, not only the last of a wave
+    int finisher_wgs = 16;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
     int finisher_polls = 4000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look)
     int quad_budget = 0;      // PAGK_QUAD_BUDGET: iterations a feature may run in the throughput kernel before it is
                               // handed to k_track_resume; 0 (default): no hand-over (profiles/r02_ab_runs.md)
@@ -407,6 +408,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
                 a.susp_waves = (n + 3) / 4;
                 a.susp_polls = ctx->finisher_polls;
+                a.susp_lone = ctx->susp_lone;
                 HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
             }
             // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (not inside a
@@ -733,6 +735,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
     if (getenv("PAGK_ROWS_WAVES")) ctx->rows_waves_cap = atoi(getenv("PAGK_ROWS_WAVES"));
     if (getenv("PAGK_FINISHER_WGS")) ctx->finisher_wgs = atoi(getenv("PAGK_FINISHER_WGS"));
+    if (getenv("PAGK_SUSPEND_LONE")) ctx->susp_lone = atoi(getenv("PAGK_SUSPEND_LONE"));
     if (getenv("PAGK_FINISHER_POLLS")) ctx->finisher_polls = atoi(getenv("PAGK_FINISHER_POLLS"));
     if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||

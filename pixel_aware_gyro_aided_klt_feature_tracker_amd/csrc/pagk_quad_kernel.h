@@ -153,7 +153,10 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             // wave here, between two iterations -- everything the loop carries (:186-194, :332-340) goes to
             // susp_state -- and is finished by k_track_resume, the latency kernel.  The slowest features (a handful
             // run 3-5x the mean iteration count) would otherwise keep a whole throughput wave, and the launch, waiting.
-            if (a.iter_budget > 0 && act && iters >= a.iter_budget && iter > 0) {
+            // (susp_lone: only a feature that is the LAST one iterating in its wave leaves -- the rows beside it are
+            // waiting for nothing else)
+            const bool lone = __popcll(__ballot(act)) == 16;  // one row of sixteen lanes
+            if (a.iter_budget > 0 && act && iters >= a.iter_budget && iter > 0 && (!a.susp_lone || lone)) {
                 if (lr == 0) {
                     // state first, then the list entry that publishes it (the finisher runs concurrently)
                     int *st = reinterpret_cast<int *>(&a.susp_state[fi]);

@@ -160,6 +160,8 @@ def test_quad_kernel_continuation(monkeypatch, budget, finisher):
         monkeypatch.setenv("PAGK_FINISHER_WGS", "0")
     if finisher == "impatient":
         monkeypatch.setenv("PAGK_FINISHER_POLLS", "0")
+    if budget in (1, 7, 12):
+        monkeypatch.setenv("PAGK_SUSPEND_LONE", "0")     # every feature leaves at the budget, not only a wave's last one
     c = capi.Context(0)
     try:
         for idx, n, h in ((1, 1003, 10), (3, 3000, 10), (1, 600, 5), (1, 600, 7)):
