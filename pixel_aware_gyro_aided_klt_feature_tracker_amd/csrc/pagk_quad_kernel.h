@@ -18,7 +18,7 @@
 //
 // Sampling is per feature (64 lanes x one pixel each, a "chunk" of 64 patch pixels at a time, skipped for a
 // feature that has left the iteration loop of the level); chunk c of all four features is sampled, then folded
-// into the MFMA and cost chains, so LDS holds one chunk: ~9.5 KB per wave, 16 waves per CU.
+// into the MFMA and cost chains, so LDS holds one chunk: 10000 B per wave, 16 waves per CU.
 //
 // The four features run the level's iterations in lockstep; a feature that converges early waits for the others
 // of its wave at the level boundary (its block / row keeps accumulating values nobody reads).  Results are
