@@ -230,17 +230,38 @@ def main() -> int:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         gather_via = "torch.distributed (RCCL backend)"
         if want_capi:
+            # Every rank must take the same branch (forming a communicator is itself a collective): each rank first
+            # checks on its own that the library can reach RCCL at all (an id of its own costs nothing), the ranks
+            # agree on that through torch.distributed, and only then is rank 0's id broadcast and the communicator
+            # formed; a failure after that point is agreed upon the same way before anyone uses the communicator.
+            def all_ok(flag: bool) -> bool:
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+            why = ""
             try:
+                my_uid = capi.Multi.unique_id()
+            except Exception as e:   # noqa: BLE001 -- any failure here must not lose the run
+                my_uid, why = None, str(e)
+            if all_ok(my_uid is not None):
                 uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(capi.Multi.unique_id()), dtype=torch.uint8))
+                    uid.copy_(torch.frombuffer(bytearray(my_uid), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
-                comm = capi.Multi(uid=bytes(uid.cpu().numpy().tobytes()), rank=rank, world=world, device=local_rank)
-                distributed.COMM = comm
-                gather_via = "pagk_multi_allgather (libpagk_hip.so -> ncclAllGather)"
-            except Exception as e:   # noqa: BLE001 -- any failure here must not lose the run
-                print(f"bench.py: library communicator unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
-                comm = None
+                try:
+                    comm = capi.Multi(uid=bytes(uid.cpu().numpy().tobytes()), rank=rank, world=world, device=local_rank)
+                except Exception as e:   # noqa: BLE001
+                    comm, why = None, str(e)
+                if all_ok(comm is not None):
+                    distributed.COMM = comm
+                    gather_via = "pagk_multi_allgather (libpagk_hip.so -> ncclAllGather)"
+                else:
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+            if comm is None:
+                print(f"bench.py: library communicator unavailable on some rank ({why or 'another rank'}); gathering "
+                      f"through torch.distributed", file=sys.stderr)
     distributed.FORCE_COLLECTIVE = force_dist
 
     # identical inputs on every rank (seeded generator)
