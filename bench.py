@@ -143,7 +143,7 @@ def config_row(cfg_idx: int, n: int, device: int, steps: int, streams: int = 1) 
                          camera=w.camera)
     cams = []
     for _ in range(streams):
-        rt = runtime.ResidentTracker(p, device=device)
+        rt = runtime.ResidentTracker(p, device=device, concurrency=streams)
         rt.load_pair(w.img_ref, w.img_cur)
         rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
         cams.append(rt)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 200 /* 0.2.0 */
+#define PAGK_VERSION 201 /* 0.2.1 */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -184,6 +184,14 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 /* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
  * -1 before the first launch. */
 int pagk_last_variant(const pagk_ctx *ctx);
+
+/* Concurrency hint for the automatic selection: the caller runs `streams` contexts like this one at the same time on
+ * this device (one PatchMatch per camera stream, BASELINE configs[4]: src/patch_match.cpp:79-142 called from several
+ * threads).  The launch-size thresholds above are then applied to streams * n: a launch that would get a latency
+ * variant on an empty device gets the throughput variant when the device is shared -- measured with eight concurrent
+ * 1280x720 x 4000 streams: 26.5 instead of 17.6 Mfeat/s in aggregate (profiles/r02_ab_runs.md).  Results do not
+ * depend on the variant.  streams = 1 (default) .. 64. */
+int pagk_set_concurrency(pagk_ctx *ctx, int32_t streams);
 
 /* Milliseconds spent in the tracking kernel(s) of the last pagk_track*_ call,
  * measured with HIP events on the stream the kernels ran on. Synchronises. */

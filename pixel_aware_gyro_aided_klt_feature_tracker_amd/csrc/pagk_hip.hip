@@ -70,6 +70,7 @@ struct pagk_ctx {
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
+    int concurrency = 1;    // pagk_set_concurrency: contexts like this one running at the same time on the device
     int last_variant = -1;  // variant the last tracking launch used (pagk_last_variant)
     // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
     // the 4-wave DPP kernel is fastest while every workgroup is resident (its latency is lowest), the
@@ -325,10 +326,11 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool mfma_ok = a.half == 5 || a.half == 7 || a.half == 10;
         // four features per wave: no NCC epilogue of its own (calc_ncc launches run the one-wave-per-feature variant)
         // ... and with the four rows of a wave independent + a work queue (pagk_rows_kernel.h)
+        const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
-        const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n >= ctx->quad_min_features));
-        const bool use_wave = !use_quad && !use_rows && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n >= ctx->wave_min_features));
-        const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n >= ctx->mfma_min_features));
+        const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
+        const bool use_wave = !use_quad && !use_rows && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
+        const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n_sel >= ctx->mfma_min_features));
         ctx->last_variant = ctx->kernel == 1 ? 1 : use_rows ? 6 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
@@ -800,6 +802,13 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 }
 
 int pagk_last_variant(const pagk_ctx *ctx) { return ctx ? ctx->last_variant : PAGK_E_ARG; }
+
+int pagk_set_concurrency(pagk_ctx *ctx, int32_t streams)
+{
+    if (!ctx || streams < 1 || streams > 64) return PAGK_E_ARG;
+    ctx->concurrency = streams;
+    return PAGK_OK;
+}
 
 int pagk_sync(pagk_ctx *ctx)
 {

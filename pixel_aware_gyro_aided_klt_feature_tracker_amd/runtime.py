@@ -18,7 +18,7 @@ class ResidentTracker:
     feature shard.  The reference frame's pyramid is the one the previous step built
     (cur of pair t is ref of pair t+1), so it is not rebuilt."""
 
-    def __init__(self, params: capi.Params, device: int = 0, rank: int = 0, world: int = 1):
+    def __init__(self, params: capi.Params, device: int = 0, rank: int = 0, world: int = 1, concurrency: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("ResidentTracker needs a HIP device (torch.cuda.is_available() is False)")
         self.params = params
@@ -26,6 +26,8 @@ class ResidentTracker:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.ctx = capi.Context(device)
+        if concurrency > 1:   # this many trackers share the device (one per camera stream): pagk_set_concurrency
+            self.ctx.set_concurrency(concurrency)
         # Two explicit streams.  `main` carries the tracking launches (and, because step() makes it torch's
         # current stream, the RCCL all-gather orders after them); `side` builds the NEXT frame's pyramid while
         # the current pair is being tracked (a new frame's pyramid depends on no tracking result).  Never the

@@ -42,7 +42,7 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
 
 def test_version_errors_defaults(built):
     lib = capi.load()
-    assert lib.pagk_version() == 200
+    assert lib.pagk_version() == 201
     assert lib.pagk_strerror(0) == b"ok" and lib.pagk_strerror(-4) == b"unsupported mode"
     p = capi.Params()
     lib.pagk_params_default(C.byref(p))

@@ -468,16 +468,19 @@ def test_config4_stream_shape_at_full_size(ctx):
     assert int(a["status"][:w.n].sum()) > 0.8 * w.n_active
 
 
-def test_config4_eight_concurrent_streams_on_one_gpu(ctx):
+@pytest.mark.parametrize("hint,variant", [(1, 2), (8, 5)])
+def test_config4_eight_concurrent_streams_on_one_gpu(ctx, hint, variant):
     """BASELINE configs[4] in its 8-stream form on ONE GPU: eight resident trackers of the 1280x720 x 4000 shape, each
     with its own streams and hipGraph, stepped interleaved (two frames each); every stream must reproduce the
-    single-stream result bit for bit."""
+    single-stream result bit for bit -- without the concurrency hint (each launch picks the 2-wave MFMA variant, as if
+    it had the device to itself) and with pagk_set_concurrency(8) (8 x 4000 features: four features per wave)."""
     w = synth.config(4)
     p = params_for(w)
     single = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    assert ctx.last_variant() == 2
     cams = []
     for _ in range(8):
-        rt = runtime.ResidentTracker(p, device=0)
+        rt = runtime.ResidentTracker(p, device=0, concurrency=hint)
         rt.load_pair(w.img_ref, w.img_cur)
         rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
         cams.append(rt)
@@ -487,8 +490,8 @@ def test_config4_eight_concurrent_streams_on_one_gpu(ctx):
     torch.cuda.synchronize()
     for k, (rt, out) in enumerate(zip(cams, outs)):
         got = distributed.to_numpy(out)
-        assert rt.mode_used == "graph" and rt.ctx.last_variant() == 2
-        assert_parity(got, single, w.n, exact=True, what=f"stream {k} of 8")
+        assert rt.mode_used == "graph" and rt.ctx.last_variant() == variant
+        assert_parity(got, single, w.n, exact=True, what=f"stream {k} of 8, concurrency hint {hint}")
     for rt in cams:
         rt.close()
 
