@@ -128,6 +128,16 @@ def test_rows_kernel_on_baseline_configs(ctx, idx, n):
     assert ctx.last_variant() == 6
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_quad_and_rows_kernels_with_fewer_features_than_rows(ctx, n):
+    # a wave whose rows outnumber the features: spare rows shadow / idle and write nothing
+    w = synth.config(1, n=n)
+    for kernel in (5, 6):
+        got, ref = run_both(ctx, params_for(w), w, kernel=kernel)
+        assert_parity(got, ref, w.n, exact=True, what=f"kernel {kernel}, {n} features")
+        assert ctx.last_variant() == kernel
+
+
 @pytest.mark.parametrize("waves", [1, 3, 64])
 def test_rows_kernel_work_queue(monkeypatch, waves):
     # a grid of `waves` wavefronts: all but the first 4 * waves features reach their row through the queue, rows of a
@@ -660,7 +670,9 @@ def test_randomized_parity_sweep(ctx, seed):
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                          camera=w.camera, **flags)
     ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
-    for kernel in (0, 1, 2, 3, 5):   # auto, thread-per-feature, MFMA 2-wave, wave-per-feature, four features per wave (fall back where not built)
+    # auto, thread-per-feature, MFMA 2-wave, wave-per-feature, four features per wave, four rows + queue (the last
+    # four fall back where a patch size is not built)
+    for kernel in (0, 1, 2, 3, 5, 6):
         ctx.set_kernel(kernel)
         try:
             got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)

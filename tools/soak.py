@@ -9,6 +9,8 @@ from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi
 import test_parity_gpu as T
 from util import assert_parity
 first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 300
+# PAGK_SOAK_KERNELS=0,2,3,5,6 (default); with PAGK_QUAD_BUDGET / PAGK_ROWS_WAVES set, the hand-over and the queue are soaked too
+KERNELS = tuple(int(k) for k in os.environ.get("PAGK_SOAK_KERNELS", "0,2,3,5,6").split(","))
 ctx = capi.Context(0)
 bad = 0
 feats = 0
@@ -17,7 +19,7 @@ for seed in range(first, first + count):
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                          camera=w.camera, **flags)
     ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
-    for kernel in (0, 2, 3):
+    for kernel in KERNELS:
         ctx.set_kernel(kernel)
         got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
         try:
@@ -29,4 +31,4 @@ for seed in range(first, first + count):
     if (seed - first) % 50 == 49:
         print(f"{seed - first + 1} cases, {feats} features, {bad} mismatches", flush=True)
 ctx.set_kernel(0)
-print(f"soak done: {count} cases x 3 kernels, {feats} features, {bad} mismatches")
+print(f"soak done: {count} cases x kernels {KERNELS}, {feats} features, {bad} mismatches")
