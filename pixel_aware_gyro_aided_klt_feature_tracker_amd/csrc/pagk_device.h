@@ -240,6 +240,44 @@ __device__ __forceinline__ float sample(const DevLevel &L, float x, float y)
 #endif
 }
 
+// One sample in two halves (tap load requested / interpolated), so that a batch of independent samples has all its
+// gathers in flight at once.  Same arithmetic as sample<CLAMP>().
+struct OneTap {
+    Taps q;
+    float fx, fy;  // the fractions xx, yy; (1 - xx) is formed at use: the same single rounding
+};
+template <bool CLAMP>
+__device__ __forceinline__ OneTap sample_issue(const DevLevel &L, float x, float y)
+{
+#ifdef PAGK_PK_BILERP
+    const CoordPk cx = prep_coord_pk<CLAMP>(x, L.fcols, L.fcols_m1);
+    const CoordPk cy = prep_coord_pk<CLAMP>(y, L.frows, L.frows_m1);
+    OneTap t;
+    t.q = load_taps(tap_src(L), __mul24(cy.i, L.cols) + cx.i);
+    t.fx = cx.w.y, t.fy = cy.w.y;
+    return t;
+#else
+    const Coord cx = prep_coord<CLAMP>(x, L.fcols, L.fcols_m1);
+    const Coord cy = prep_coord<CLAMP>(y, L.frows, L.frows_m1);
+    OneTap t;
+    t.q = L.quad[(uint32_t)(__mul24(cy.i, L.cols) + cx.i)];
+    t.fx = cx.f, t.fy = cy.f;
+    return t;
+#endif
+}
+__device__ __forceinline__ float sample_finish(const OneTap &t)
+{
+#ifdef PAGK_PK_BILERP
+    pagk_f32x2 wx, wy;
+    wx.x = 1.0f - t.fx, wx.y = t.fx;
+    wy.x = 1.0f - t.fy, wy.y = t.fy;
+    return bilerp_pk(taps_f32(t.q), wx, wy);
+#else
+    const Coord cx{0, t.fx, 1.0f - t.fx}, cy{0, t.fy, 1.0f - t.fy};
+    return bilerp(t.q, cx, cy);
+#endif
+}
+
 // The five img2 samples one pixel of the GN loop needs (src/patch_match.cpp:252,259-262):
 // centre, x+1, x-1, y+1, y-1.  Each coordinate is prepared once (X+-1 share Y and vice versa).
 struct Five {

@@ -135,13 +135,19 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         // ... kept in this wave's slice of the global workspace (4 x NCH x 64 floats, read back coalesced, one load
         // per sampled pixel): 28 registers at h = 10 that would otherwise spill
         float *ws = a.ws + (size_t)blockIdx.x * (4 * NCH * 64) + lane;
+        // (a feature's NCH gathers are requested together: one round trip per feature instead of one per chunk)
+#pragma nounroll
         for (int f = 0; f < 4; f++) {
             const float fx = rl(ptx, 16 * f), fy = rl(pty, 16 * f);
+            OneTap t1[NCH];
+#pragma unroll
             for (int c = 0; c < NCH; c++) {
                 float x, y;
                 patch_xy(c, x, y);
-                ws[(f * NCH + c) * 64] = sample<true>(L1, fx + x, fy + y);
+                t1[c] = sample_issue<true>(L1, fx + x, fy + y);
             }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) ws[(f * NCH + c) * 64] = sample_finish(t1[c]);
         }
         __syncthreads();  // the previous level's readers of cconst are done
         S.cconst[row][lr] = cd;
