@@ -15,6 +15,7 @@
 // multiply-add orders agree), stage them in LDS, and then one 16-lane DPP row per accumulator entry
 // walks its stream at the dependent-FMA latency (5.9 cycles per pixel, pagk_chain_asm.h).
 #pragma once
+#include <type_traits>
 #include "pagk_device.h"
 #include "pagk_chain_asm.h"
 
@@ -679,7 +680,16 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             // a valid pixel and simply do not store)
             // the gathers of up to two rounds are in flight at a time (a tap costs up to four registers until it is
             // interpolated): NR = 2 issues everything up front, NR = 4 works in two groups
+            // The clamp-free and the clamped form are two copies of the whole phase, chosen once: with the choice inside
+            // (`interior ? issue<false> : issue<true>` per round) the two forms' loads share destination registers on
+            // a control-flow path that cannot happen, and the compiler waits for every load in flight before each
+            // round's gathers -- the rounds ran one after the other (profiles/r02_ab_runs.md).
             constexpr int G = NR < 2 ? NR : 2;
+            // Measured (same session, tools/ab_lib.py): 4-wave kernel -2.9 % at 250 features, -2.7 % at 1000, -2.2 % on
+            // configs[2]; the 2-wave MFMA kernel (four rounds) +1.5 % (13 more spilled registers), so it keeps the choice
+            // per round (mode 2).
+            auto sampling = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;  // 0: clamp-free, 1: clamped, 2: chosen per round
 #pragma unroll
             for (int r0 = 0; r0 < NR; r0 += G) {
                 FiveTaps taps[G];
@@ -687,7 +697,10 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                 for (int u = 0; u < G; u++) {
                     const int r = r0 + u < NR ? r0 + u : NR - 1;
                     float X = bx + wx[r], Y = by + wy[r];
-                    taps[u] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+                    if constexpr (MODE == 2)
+                        taps[u] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
+                    else
+                        taps[u] = sample5_issue<MODE == 1>(L2, X, Y);
 #ifdef PAGK_STAMPS
                     if (r0 == 0 && u == 0) {
                         STAMP(13)  // first round's coordinates computed and gathers issued
@@ -730,6 +743,13 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                     }
                 }
             }
+            };
+            if constexpr (MFMA)
+                sampling(std::integral_constant<int, 2>{});
+            else if (interior)
+                sampling(std::integral_constant<int, 0>{});
+            else
+                sampling(std::integral_constant<int, 1>{});
 #ifdef PAGK_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             STAMP(10)  // interpolation, products, LDS stores done in this wave

@@ -18,6 +18,7 @@
 //   4. solve + update in lane 0 / every lane, as in k_track_block.
 // Bit-identical to the oracle and to the other variants (tests/test_parity_gpu.py).
 #pragma once
+#include <type_traits>
 #include "pagk_chain_asm.h"
 #include "pagk_device.h"
 
@@ -144,32 +145,41 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
             const float gain = 1.0f + dg;
             const bool interior = (bx - ext_x >= 0.0f) && (bx + ext_x < L2.fcols_m1) &&
                                   (by - ext_y >= 0.0f) && (by + ext_y < L2.frows_m1);
+            // two rounds' gathers in flight at a time; the clamp-free / clamped choice is made once for the phase, not
+            // per round (see k_track_block: chosen per round, the compiler serialises the rounds)
+            auto sampling = [&](auto clamp_tag) {
+                constexpr bool CLAMP = decltype(clamp_tag)::value;
 #pragma unroll
-            for (int r0 = 0; r0 < NR; r0 += 2) {  // two rounds' gathers in flight at a time
-                Five smp[2];
+                for (int r0 = 0; r0 < NR; r0 += 2) {
+                    FiveTaps taps[2];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int r = r0 + u < NR ? r0 + u : NR - 1;
-                    float X = bx + wx[r], Y = by + wy[r];
-                    smp[u] = interior ? sample5<false>(L2, X, Y) : sample5<true>(L2, X, Y);
-                }
+                    for (int u = 0; u < 2; u++) {
+                        const int r = r0 + u < NR ? r0 + u : NR - 1;
+                        float X = bx + wx[r], Y = by + wy[r];
+                        taps[u] = sample5_issue<CLAMP>(L2, X, Y);
+                    }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int r = r0 + u;
-                    if (r < NR) {
-                        const int p = lane + 64 * r;
-                        if (p < P) {
-                            const Five &s = smp[u];
-                            float e = s.c + db - gain * s1[r];  // :252-253
-                            float Ix = 0.5f * (s.xp - s.xm);    // :259-260
-                            float Iy = 0.5f * (s.yp - s.ym);    // :261-262
-                            fs[0 * PS + p] = Ix;
-                            fs[1 * PS + p] = Iy;
-                            fs[2 * PS + p] = -e;
+                    for (int u = 0; u < 2; u++) {
+                        const int r = r0 + u;
+                        if (r < NR) {
+                            const Five s = sample5_finish(taps[u]);
+                            const int p = lane + 64 * r;
+                            if (p < P) {
+                                float e = s.c + db - gain * s1[r];  // :252-253
+                                float Ix = 0.5f * (s.xp - s.xm);    // :259-260
+                                float Iy = 0.5f * (s.yp - s.ym);    // :261-262
+                                fs[0 * PS + p] = Ix;
+                                fs[1 * PS + p] = Iy;
+                                fs[2 * PS + p] = -e;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (interior)
+                sampling(std::false_type{});
+            else
+                sampling(std::true_type{});
             __syncthreads();
             __builtin_amdgcn_s_setprio(3);  // chain + solve first (see k_track_block); -2 % at 20000 features
             // ---- 2. H and b: ordered MFMA chain -------------------------------------------------
