@@ -85,6 +85,23 @@ def test_create_without_device_fails_loudly(built):
         capi.Context(0)
 
 
+def test_context_setters_reject_a_null_context_and_bad_values(built):
+    # no device needed: argument checks come first (PAGK_E_ARG), nothing is dereferenced
+    lib = capi.load()
+    for fn in (lib.pagk_set_kernel, lib.pagk_set_concurrency):
+        assert fn(None, 1) == capi.PAGK_E_ARG
+    assert lib.pagk_last_variant(None) == capi.PAGK_E_ARG
+    if torch.cuda.is_available():
+        c = capi.Context(0)
+        for bad in (0, -1, 65):
+            assert c.lib.pagk_set_concurrency(c.h, bad) == capi.PAGK_E_ARG
+        for bad in (-1, 7):
+            assert c.lib.pagk_set_kernel(c.h, bad) == capi.PAGK_E_ARG
+        c.set_concurrency(8)
+        c.set_concurrency(1)
+        c.close()
+
+
 def test_missing_library_is_an_error(built, monkeypatch):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libpagk_hip.so")
