@@ -28,10 +28,8 @@ wi = d[:, 6]
 it = out["iters"][:w.n]
 print(f"cfg{cfg} n={w.n}: kernel {trk*1e3:.1f} us (stamped build), {len(d)} waves, wave-iterations mean {wi.mean():.1f} "
       f"(features: mean {it[w.status_in > 0].mean():.1f} iterations)")
-if kern == 6:
-    d[:, 5] = 1
 names = ["level setup", "sampling", "MFMA chain", "cost chain", "solve+update", "total"]
-for k in range(6):
+for k in range(6 if kern == 5 else 0):   # k_track_rows records the timeline only
     per = d[:, k] / (wi if k in (1, 2, 3, 4) else 1)
     print(f"  {names[k]:13s}: {100 * d[:, k].sum() / d[:, 5].sum():5.1f} %  mean {d[:, k].mean():10.0f} cycles/wave"
           + (f"  {per.mean():8.0f} cycles per wave-iteration" if k in (1, 2, 3, 4) else ""))
