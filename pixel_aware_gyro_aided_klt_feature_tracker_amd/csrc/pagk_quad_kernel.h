@@ -265,39 +265,46 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
                 QSTAMP(1)
-                // ---- H, b: one MFMA per four pixels, all four features ---------------------------------
-                {
-                    const int left = P - 64 * c;                   // valid pixels from this chunk on
-                    const int ng = left >= 64 ? 16 : (left >> 2);  // complete groups of four
-                    const double *pa = a_src, *pb = b_src;
-                    int m = 0;
-                    for (; m + 4 <= ng; m += 4) {
-                        double av[4], bv[4];
+                // ---- H, b and cost of the chunk.  A full chunk (64 pixels, 16 MFMA groups): one instruction stream in
+                // which the four DPP cost adds of a group sit between two dependent MFMAs (pagk_chain_asm.h:
+                // quad_chunk_full); the patch's last, shorter chunk: MFMA chain, then cost chain.
+                if (P - 64 * c >= 64) {
+                    carry = quad_chunk_full(d, lds_off(a_src), lds_off(b_src), 8u * (uint32_t)a_step, 8u * (uint32_t)b_step, sq_addr);
+                } else {
+                    // ---- H, b: one MFMA per four pixels, all four features ---------------------------------
+                    {
+                        const int left = P - 64 * c;                   // valid pixels from this chunk on
+                        const int ng = left >> 2;                      // complete groups of four (< 16)
+                        const double *pa = a_src, *pb = b_src;
+                        int m = 0;
+                        for (; m + 4 <= ng; m += 4) {
+                            double av[4], bv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            av[u] = pa[4 * u];
-                            bv[u] = pb[4 * u];
+                            for (int u = 0; u < 4; u++) {
+                                av[u] = pa[4 * u];
+                                bv[u] = pb[4 * u];
+                            }
+                            pa += a_step;
+                            pb += b_step;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
                         }
-                        pa += a_step;
-                        pb += b_step;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
+                        for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
+                        if (left & 3) {
+                            // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
+                            const int u = ng & 3;
+                            const bool pad = mk >= (left & 3);
+                            const double av = pa[4 * u], bv = pb[4 * u];
+                            d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
+                        }
                     }
-                    for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
-                    if (left < 64 && (left & 3)) {
-                        // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
-                        const int u = ng & 3;
-                        const bool pad = mk >= (left & 3);
-                        const double av = pa[4 * u], bv = pb[4 * u];
-                        d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
-                    }
-                }
 #ifdef PAGK_STAMPS
-                asm volatile("" : "+v"(d));
-                QSTAMP(2)
+                    asm volatile("" : "+v"(d));
+                    QSTAMP(2)
 #endif
-                // ---- cost: ordered f32 sum, row q = feature q ----------------------------------------
-                carry = chain_rows_f32<1>(sq_addr, 128u, 2);
+                    // ---- cost: ordered f32 sum, row q = feature q ----------------------------------------
+                    carry = chain_rows_f32<1>(sq_addr, 128u, 2);
+                }
                 __syncthreads();  // the chunk has been read before the next one is written
                 QSTAMP(3)
             }
