@@ -12,7 +12,8 @@
 //            instruction per four pixels for FOUR features, operands read from LDS already widened (the widening
 //            is done once per pixel by the sampling lanes, 64 useful lanes per instruction);
 //   cost     the ordered f32 sum of e*e (:294) is a 16-lane DPP row chain: the wave's four rows are the four
-//            features, one instruction stream;
+//            features, one instruction stream -- for a full chunk interleaved into the MFMA chain (four adds
+//            between two dependent MFMAs: pagk_chain_asm.h, quad_chunk_full);
 //   solve    lane = feature: every lane of row q runs feature q's 4x4 LLT / solve / update (:302-344); four
 //            different solves share each f64 divide and sqrt sequence.
 //
