@@ -178,6 +178,9 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  *     it exists to measure what the ordered accumulation costs.
  * 5 = four features per wavefront (block q of the f64 MFMA, row q of the cost chain and lane = feature solve shared
  *     by four features): a throughput variant for very large launches; bit-identical like 0-3.
+ *     A launch of this variant that would end with an exposed tail (0.45 to 1.25 rounds of resident waves, the
+ *     context alone on the device, not inside a graph capture) hands the features that have run 20 iterations to the
+ *     4-wave latency kernel, which runs beside it on the context's auxiliary stream; results are the same bits.
  * 6 = 5 with the four rows of a wave independent (each row runs its own feature at its own level and takes the next
  *     feature from a work queue when it is done; a resident grid): bit-identical like 0-3. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);

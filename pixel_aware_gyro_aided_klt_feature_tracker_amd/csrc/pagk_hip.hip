@@ -59,8 +59,10 @@ struct pagk_ctx {
     int susp_lone = 1;        // PAGK_SUSPEND_LONE=0: hand every feature over at the budget, not only the last of a wave
     int finisher_wgs = 16;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
     int finisher_polls = 4000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look)
-    int quad_budget = 0;      // PAGK_QUAD_BUDGET: iterations a feature may run in the throughput kernel before it is
-                              // handed to k_track_resume; 0 (default): no hand-over (profiles/r02_ab_runs.md)
+    int quad_budget = -1;     // iterations a feature may run in the four-features-per-wave kernel before it is handed to
+                              // the latency kernel; 0: never; -1 (default): chosen per launch, see quad_budget_for().
+                              // PAGK_QUAD_BUDGET overrides.
+    int cus = 0;              // compute units of the device
     // hipGraph capture of the per-frame work (pagk_graph_*): while capturing, nothing may allocate and the
     // timing events are left out (an event recorded into a graph cannot be read back)
     bool capturing = false;
@@ -268,6 +270,22 @@ void fill_level(DevLevel &d, const FrameSlot &s, int l)
 // pyr / pyr_blocks / pyr_done: optionally, another slot's pyramid to be built by trailing workgroups of the
 // tracking launch (k_track_block_pyr).  Honoured when the 4-wave kernel is the one selected; *pyr_done tells the
 // caller whether it was (otherwise the caller launches the pyramid itself).
+// Hand-over budget of a four-features-per-wave launch of `waves` wavefronts.  The hand-over pays where the launch ends
+// with an exposed tail -- between half a round and 1.25 rounds of resident waves (16 per CU): a handful of features
+// with 3-5x the mean iteration count would otherwise each keep a wave alive long after the rest has finished
+// (configs[3], 20000 features: -6 %; 8000: -4 %).  With a fuller second round the first round's stragglers are already
+// hidden behind it and the finisher only displaces throughput waves (30000: +8 %), and a context that shares the device
+// (pagk_set_concurrency) has other launches to fill its tail.  profiles/r02_ab_runs.md.
+int quad_budget_for(const pagk_ctx *ctx, int waves)
+{
+    if (ctx->quad_budget >= 0) return ctx->quad_budget;
+    const long long cap = 16ll * (ctx->cus > 0 ? ctx->cus : 256);
+    const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
+    // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
+    // finisher that starts after the throughput kernel is the plain sweep: +13 %)
+    return (ctx->concurrency == 1 && exposed_tail && !ctx->capturing) ? 20 : 0;
+}
+
 int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
                  const float *d_pt_ref, const float *d_pt_init, const float *d_affine, const uint8_t *d_status,
                  const pagk_outputs *o, const PyrArgs *pyr = nullptr, int pyr_blocks = 0, bool *pyr_done = nullptr)
@@ -389,7 +407,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             }
             a.ws = static_cast<float *>(ctx->quad_ws);
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
-            const bool handover = ctx->quad_budget > 0;
+            const int budget = quad_budget_for(ctx, (n + 3) / 4);
+            const bool handover = budget > 0;
             if (handover) {
                 const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
                 if (need_s > ctx->susp_bytes) {
@@ -404,7 +423,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     ctx->susp_bytes = need_s;
                 }
                 uint8_t *sb = static_cast<uint8_t *>(ctx->susp);
-                a.iter_budget = ctx->quad_budget;
+                a.iter_budget = budget;
                 a.susp_count = reinterpret_cast<int *>(sb);
                 a.susp_list = reinterpret_cast<int *>(sb + 256);
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
@@ -413,9 +432,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_lone = ctx->susp_lone;
                 HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
             }
-            // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (not inside a
-            // graph capture: there the sweep alone finishes the suspended features)
-            const bool live = handover && ctx->finisher_wgs > 0 && !ctx->capturing && ctx->aux_stream;
+            // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (inside a graph
+            // capture the auxiliary stream joins the capture through the fork event: a parallel branch of the graph)
+            const bool live = handover && ctx->finisher_wgs > 0 && ctx->aux_stream;
             if (live) {
                 HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -726,6 +745,7 @@ int pagk_create(pagk_ctx **out, int device)
         return PAGK_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->cus = 0;
     if (hipMalloc(&ctx->queue, 256) != hipSuccess) {
         pagk_destroy(ctx);
         return PAGK_E_NOMEM;

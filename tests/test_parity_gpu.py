@@ -506,6 +506,38 @@ def test_config4_eight_concurrent_streams_on_one_gpu(ctx, hint, variant):
         rt.close()
 
 
+def test_config3_direct_and_graph_steps_with_and_without_hand_over(ctx, monkeypatch):
+    """BASELINE configs[3] on one GPU: 5000 waves of the four-features-per-wave kernel are 1.2 rounds of resident
+    waves, so a direct launch hands features past the iteration budget to the latency kernel running beside it
+    (automatic rule, quad_budget_for); a captured graph does not (its branches replay one after the other), unless
+    forced -- then the finisher is a parallel branch of the graph (auxiliary stream joined through the fork event).
+    All four ways give the same bits as the launch with the hand-over switched off."""
+    w = synth.config(3)
+    p = params_for(w)
+    monkeypatch.setenv("PAGK_QUAD_BUDGET", "0")
+    c = capi.Context(0)
+    try:
+        ref = c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    finally:
+        c.close()
+    for forced in (None, "20"):
+        if forced is None:
+            monkeypatch.delenv("PAGK_QUAD_BUDGET")
+        else:
+            monkeypatch.setenv("PAGK_QUAD_BUDGET", forced)
+        rt = runtime.ResidentTracker(p, device=0)
+        rt.load_pair(w.img_ref, w.img_cur)
+        rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+        for mode in ("serial", "graph"):
+            out = None
+            for _ in range(2):
+                out = rt.step(mode=mode)
+            torch.cuda.synchronize()
+            assert rt.mode_used == mode and rt.ctx.last_variant() == 5
+            assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what=f"configs[3] {mode} step, budget {forced or 'auto'}")
+        rt.close()
+
+
 # ---- full-size properties (sizes the oracle would take too long to check in full) ---------------
 def test_full_size_properties_1080p_20000(ctx):
     w = synth.config(3)  # 1920x1080, 20000 keypoints
