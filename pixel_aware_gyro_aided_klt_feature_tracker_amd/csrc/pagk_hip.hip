@@ -276,9 +276,12 @@ void fill_level(DevLevel &d, const FrameSlot &s, int l)
 // (configs[3], 20000 features: -6 %; 8000: -4 %).  With a fuller second round the first round's stragglers are already
 // hidden behind it and the finisher only displaces throughput waves (30000: +8 %), and a context that shares the device
 // (pagk_set_concurrency) has other launches to fill its tail.  profiles/r02_ab_runs.md.
-int quad_budget_for(const pagk_ctx *ctx, int waves)
+int quad_budget_for(const pagk_ctx *ctx, int waves, int iterations, int levels)
 {
     if (ctx->quad_budget >= 0) return ctx->quad_budget;
+    // a feature can run iterations x levels iterations at most: with the reference's own call site (10 x 3) nothing
+    // runs long enough past the budget for the hand-over to pay for its list reset, finisher launch and sweep
+    if (iterations * levels < 60) return 0;
     const long long cap = 16ll * (ctx->cus > 0 ? ctx->cus : 256);
     const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
     // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
@@ -407,7 +410,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             }
             a.ws = static_cast<float *>(ctx->quad_ws);
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
-            const int budget = quad_budget_for(ctx, (n + 3) / 4);
+            const int budget = quad_budget_for(ctx, (n + 3) / 4, p->iterations, p->pyramids);
             const bool handover = budget > 0;
             if (handover) {
                 const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
