@@ -58,7 +58,8 @@ struct pagk_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int susp_lone = 1;        // PAGK_SUSPEND_LONE=0: hand every feature over at the budget, not only the last of a wave
     int finisher_wgs = 16;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
-    int finisher_polls = 4000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look)
+    int finisher_polls = 20000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look: ~35 ms,
+                                 // an order of magnitude beyond the longest launch the hand-over rule admits)
     int quad_budget = -1;     // iterations a feature may run in the four-features-per-wave kernel before it is handed to
                               // the latency kernel; 0: never; -1 (default): chosen per launch, see quad_budget_for().
                               // PAGK_QUAD_BUDGET overrides.
