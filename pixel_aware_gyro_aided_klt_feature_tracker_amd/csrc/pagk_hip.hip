@@ -287,7 +287,11 @@ int quad_budget_for(const pagk_ctx *ctx, int waves, int iterations, int levels)
     const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
     // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
     // finisher that starts after the throughput kernel is the plain sweep: +13 %)
-    return (ctx->concurrency == 1 && exposed_tail && !ctx->capturing) ? 20 : 0;
+    if (ctx->concurrency != 1 || !exposed_tail || ctx->capturing) return 0;
+    // the caller's own capture of the stream (not through pagk_graph_begin) counts as well
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    return 20;
 }
 
 int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
