@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 201 /* 0.2.1 */
+#define PAGK_VERSION 202 /* 0.2.2 */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -187,6 +187,10 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 /* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
  * -1 before the first launch. */
 int pagk_last_variant(const pagk_ctx *ctx);
+
+/* Number of features the last tracking launch of this context handed from the throughput kernel to the latency
+ * kernel (variant 5, see above); 0 when the launch did not use the hand-over.  Synchronises the context's stream. */
+int pagk_last_handover(pagk_ctx *ctx);
 
 /* Concurrency hint for the automatic selection: the caller runs `streams` contexts like this one at the same time on
  * this device (one PatchMatch per camera stream, BASELINE configs[4]: src/patch_match.cpp:79-142 called from several

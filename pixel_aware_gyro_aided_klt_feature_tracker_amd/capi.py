@@ -162,6 +162,8 @@ def declare(lib) -> None:
     lib.pagk_last_variant.argtypes = [vp]
     lib.pagk_set_concurrency.restype = C.c_int
     lib.pagk_set_concurrency.argtypes = [vp, i32]
+    lib.pagk_last_handover.restype = C.c_int
+    lib.pagk_last_handover.argtypes = [vp]
     lib.pagk_last_kernel_ms.restype = C.c_int
     lib.pagk_last_kernel_ms.argtypes = [vp, _P(C.c_float), _P(C.c_float)]
     lib.pagk_gyro_predict_device.restype = C.c_int
@@ -229,7 +231,7 @@ EXPORTED_SYMBOLS = [
     "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
     "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_track_device_fused", "pagk_sync",
-    "pagk_set_stream", "pagk_set_kernel", "pagk_last_variant", "pagk_set_concurrency", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
+    "pagk_set_stream", "pagk_set_kernel", "pagk_last_variant", "pagk_set_concurrency", "pagk_last_handover", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
     "pagk_gyro_predict_device_rot",
     "pagk_geometry_scores_device", "pagk_geometry_scores", "pagk_geometry_select", "pagk_geometry_validation",
     "pagk_graph_begin", "pagk_graph_end", "pagk_graph_launch", "pagk_graph_destroy",
@@ -480,6 +482,13 @@ class Context:
 
     def last_variant(self) -> int:
         return int(self.lib.pagk_last_variant(self.h))
+
+    def last_handover(self) -> int:
+        """Features the last launch handed from the throughput kernel to the latency kernel (0: hand-over not used)."""
+        rc = int(self.lib.pagk_last_handover(self.h))
+        if rc < 0:
+            self._check(rc, "pagk_last_handover")
+        return rc
 
     def set_concurrency(self, streams: int):
         """`streams` contexts like this one run at the same time on the device: the automatic variant thresholds are

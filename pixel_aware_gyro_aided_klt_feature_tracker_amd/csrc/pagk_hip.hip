@@ -73,6 +73,7 @@ struct pagk_ctx {
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
+    bool last_handover = false;  // the last tracking launch used the hand-over (pagk_last_handover)
     int concurrency = 1;    // pagk_set_concurrency: contexts like this one running at the same time on the device
     int last_variant = -1;  // variant the last tracking launch used (pagk_last_variant)
     // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
@@ -352,6 +353,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool mfma_ok = a.half == 5 || a.half == 7 || a.half == 10;
         // four features per wave: no NCC epilogue of its own (calc_ncc launches run the one-wave-per-feature variant)
         // ... and with the four rows of a wave independent + a work queue (pagk_rows_kernel.h)
+        ctx->last_handover = false;
         const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
         const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
@@ -417,6 +419,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
             const int budget = quad_budget_for(ctx, (n + 3) / 4, p->iterations, p->pyramids);
             const bool handover = budget > 0;
+            ctx->last_handover = handover;
             if (handover) {
                 const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
                 if (need_s > ctx->susp_bytes) {
@@ -830,6 +833,17 @@ int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 }
 
 int pagk_last_variant(const pagk_ctx *ctx) { return ctx ? ctx->last_variant : PAGK_E_ARG; }
+
+int pagk_last_handover(pagk_ctx *ctx)
+{
+    if (!ctx) return PAGK_E_ARG;
+    if (!ctx->last_handover || !ctx->susp) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int count = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&count, ctx->susp, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return count;
+}
 
 int pagk_set_concurrency(pagk_ctx *ctx, int32_t streams)
 {

@@ -42,7 +42,7 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
 
 def test_version_errors_defaults(built):
     lib = capi.load()
-    assert lib.pagk_version() == 201
+    assert lib.pagk_version() == 202
     assert lib.pagk_strerror(0) == b"ok" and lib.pagk_strerror(-4) == b"unsupported mode"
     p = capi.Params()
     lib.pagk_params_default(C.byref(p))
@@ -90,7 +90,7 @@ def test_context_setters_reject_a_null_context_and_bad_values(built):
     lib = capi.load()
     for fn in (lib.pagk_set_kernel, lib.pagk_set_concurrency):
         assert fn(None, 1) == capi.PAGK_E_ARG
-    assert lib.pagk_last_variant(None) == capi.PAGK_E_ARG
+    assert lib.pagk_last_variant(None) == capi.PAGK_E_ARG and lib.pagk_last_handover(None) == capi.PAGK_E_ARG
     if torch.cuda.is_available():
         c = capi.Context(0)
         for bad in (0, -1, 65):

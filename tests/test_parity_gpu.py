@@ -534,8 +534,32 @@ def test_config3_direct_and_graph_steps_with_and_without_hand_over(ctx, monkeypa
                 out = rt.step(mode=mode)
             torch.cuda.synchronize()
             assert rt.mode_used == mode and rt.ctx.last_variant() == 5
+            if mode == "serial":     # the rule: a direct launch of 1.2 rounds hands its stragglers over (max 62 iterations)
+                assert 20 < rt.ctx.last_handover() < 0.05 * w.n
             assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what=f"configs[3] {mode} step, budget {forced or 'auto'}")
         rt.close()
+
+
+def test_hand_over_rule_by_launch_size(ctx):
+    # quad_budget_for: between 0.45 and 1.25 rounds of resident waves, alone on the device, iteration cap >= 60
+    for n, expect in ((6000, False), (8000, True), (30000, False)):
+        w = synth.config(3, n=n)
+        ctx.set_kernel(5)
+        try:
+            ctx.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+            assert (ctx.last_handover() > 0) == expect, n
+            if expect:
+                ctx.set_concurrency(8)          # a context that shares the device never hands over
+                ctx.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+                assert ctx.last_handover() == 0
+                ctx.set_concurrency(1)
+                p10 = capi.make_params(half_patch=w.half_patch, iterations=10, pyramids=w.pyramids, has_gyro=w.has_gyro,
+                                       camera=w.camera)   # the reference's own 10 x 3: no room for stragglers
+                ctx.track(p10, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+                assert ctx.last_handover() == 0
+        finally:
+            ctx.set_concurrency(1)
+            ctx.set_kernel(0)
 
 
 # ---- full-size properties (sizes the oracle would take too long to check in full) ---------------
