@@ -196,7 +196,7 @@ int pagk_last_handover(pagk_ctx *ctx);
  * this device (one PatchMatch per camera stream, BASELINE configs[4]: src/patch_match.cpp:79-142 called from several
  * threads).  The launch-size thresholds above are then applied to streams * n: a launch that would get a latency
  * variant on an empty device gets the throughput variant when the device is shared -- measured with eight concurrent
- * 1280x720 x 4000 streams: 26.5 instead of 17.6 Mfeat/s in aggregate (profiles/r02_ab_runs.md).  Results do not
+ * 1280x720 x 4000 streams: 26-29 instead of 17.6 Mfeat/s in aggregate (profiles/r02_ab_runs.md).  Results do not
  * depend on the variant.  streams = 1 (default) .. 64. */
 int pagk_set_concurrency(pagk_ctx *ctx, int32_t streams);
 
