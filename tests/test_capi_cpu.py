@@ -25,8 +25,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(capi.EXPORTED_SYMBOLS)
 
 
-def test_header_is_plain_c_and_links_from_c(built, tmp_path):
-    # include/pagk.h must compile as C, and a C program must be able to drive the library
+def _build_and_run_c_smoke(tmp_path):
     import subprocess
     inc = os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
@@ -38,6 +37,20 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
                    check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    return r.stdout
+
+
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    # include/pagk.h must compile as C, and a C program must be able to drive the library
+    out = _build_and_run_c_smoke(tmp_path)
+    assert ("device present" in out) == torch.cuda.is_available()
+
+
+@pytest.mark.gpu
+def test_c_program_drives_the_library_on_the_device(built, tmp_path):
+    # the same plain-C consumer on the GPU box: its "device present" branch (argument checks through a live context,
+    # PAGK_E_UNSUPPORTED for the inverse mode) runs under `-m gpu`
+    assert "device present" in _build_and_run_c_smoke(tmp_path)
 
 
 def test_version_errors_defaults(built):
