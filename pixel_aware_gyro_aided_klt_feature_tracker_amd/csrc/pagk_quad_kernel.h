@@ -50,6 +50,73 @@ __device__ __forceinline__ double (*quad_acc(QuadLds &S))[16] { return reinterpr
 
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
+// ---- shared by k_track_quad and k_track_rows -----------------------------------------------------------------------
+// MFMA operand roles of a lane (layout measured: A(q,i,k) in lane 16k+4q+i, B(q,k,j) in lane 16k+4q+j, D(q,i,j) in lane
+// 16i+4q+j): k = pixel within the group of four, q = block = feature / row, i = entry.
+//   A = J = (Ix, Iy, c, 1)[i]      B = (Ix, Iy, -e, c)[i]
+struct QuadOperands {
+    const double *a_src, *b_src;
+    int a_step, b_step;  // doubles per four groups: 16 for a lane that walks a stream, 0 for one that re-reads constants
+    int mk, mq, mi;
+};
+__device__ __forceinline__ QuadOperands quad_operands(QuadLds &S, int lane)
+{
+    QuadOperands o;
+    o.mk = lane >> 4, o.mq = (lane >> 2) & 3, o.mi = lane & 3;
+    o.a_src = o.mi < 2 ? &S.chunk[o.mi][o.mq][o.mk] : (o.mi == 2 ? &S.cconst[o.mq][o.mk] : &S.ones[o.mk]);
+    o.b_src = o.mi < 3 ? &S.chunk[o.mi][o.mq][o.mk] : &S.cconst[o.mq][o.mk];
+    o.a_step = o.mi < 2 ? 16 : 0;
+    o.b_step = o.mi < 3 ? 16 : 0;
+    return o;
+}
+
+// H, b and cost of chunk c (after the barrier that publishes the chunk).  A full chunk (64 pixels, 16 MFMA groups): one
+// instruction stream in which the four DPP cost adds of a group sit between two dependent MFMAs (pagk_chain_asm.h:
+// quad_chunk_full); the patch's last, shorter chunk: the MFMA chain, then the cost chain.  Returns the rows' running cost.
+__device__ __forceinline__ float quad_chunk_phase(const QuadOperands &o, int P, int c, uint32_t sq_addr, double &d)
+{
+    const int left = P - 64 * c;  // valid pixels from this chunk on
+    if (left >= 64)
+        return quad_chunk_full(d, lds_off(o.a_src), lds_off(o.b_src), 8u * (uint32_t)o.a_step, 8u * (uint32_t)o.b_step, sq_addr);
+    const int ng = left >> 2;     // complete groups of four (< 16)
+    const double *pa = o.a_src, *pb = o.b_src;
+    int m = 0;
+    for (; m + 4 <= ng; m += 4) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            av[u] = pa[4 * u];
+            bv[u] = pb[4 * u];
+        }
+        pa += o.a_step;
+        pb += o.b_step;
+#pragma unroll
+        for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
+    }
+    for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
+    if (left & 3) {
+        // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
+        const int u = ng & 3;
+        const bool pad = o.mk >= (left & 3);
+        const double av = pa[4 * u], bv = pb[4 * u];
+        d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
+    }
+    return chain_rows_f32<1>(sq_addr, 128u, 2);  // cost: ordered f32 sum, row q = feature q
+}
+
+// The normal equations of this lane's row from the accumulators (:302-319): D(q, i, j) sits in lane 16 i + 4 q + j; the
+// caller has synchronised after quad_acc(S)[mq][mk * 4 + mi] = d.
+__device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, double cd, double (&H)[4][4], double (&b)[4])
+{
+    const double *A = quad_acc(S)[row];
+    H[0][0] = A[0], H[1][0] = A[4], H[1][1] = A[5];
+    H[2][0] = A[8], H[2][1] = A[9], H[2][2] = A[11];
+    H[3][0] = A[12], H[3][1] = A[13];
+    H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
+    H[3][3] = (double)P;       // sum of 1.0*1.0
+    b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
@@ -85,13 +152,8 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         y = (float)(yy - h);
     };
 
-    // MFMA operand roles of this lane (layout measured: A(q,i,k) in lane 16k+4q+i, B(q,k,j) in lane 16k+4q+j,
-    // D(q,i,j) in lane 16i+4q+j): k = pixel within the group of four, q = block = feature, i = entry.
-    //   A = (Ix, Iy, c, 1)[i]   B = (Ix, Iy, -e, c)[i]
-    const int mk = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
-    const double *a_src = mi < 2 ? &S.chunk[mi][mq][mk] : (mi == 2 ? &S.cconst[mq][mk] : &S.ones[mk]);
-    const double *b_src = mi < 3 ? &S.chunk[mi][mq][mk] : &S.cconst[mq][mk];
-    const int a_step = mi < 2 ? 16 : 0, b_step = mi < 3 ? 16 : 0;  // doubles per four groups
+    const QuadOperands ops = quad_operands(S, lane);  // MFMA operand roles of this lane
+    const int mk = ops.mk, mq = ops.mq, mi = ops.mi;
     if (lane < 32) S.ones[lane] = 1.0;
     const uint32_t sq_addr = lds_off(&S.sq[row * 129]) + 8u * lr;
 
@@ -266,46 +328,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
                 QSTAMP(1)
-                // ---- H, b and cost of the chunk.  A full chunk (64 pixels, 16 MFMA groups): one instruction stream in
-                // which the four DPP cost adds of a group sit between two dependent MFMAs (pagk_chain_asm.h:
-                // quad_chunk_full); the patch's last, shorter chunk: MFMA chain, then cost chain.
-                if (P - 64 * c >= 64) {
-                    carry = quad_chunk_full(d, lds_off(a_src), lds_off(b_src), 8u * (uint32_t)a_step, 8u * (uint32_t)b_step, sq_addr);
-                } else {
-                    // ---- H, b: one MFMA per four pixels, all four features ---------------------------------
-                    {
-                        const int left = P - 64 * c;                   // valid pixels from this chunk on
-                        const int ng = left >> 2;                      // complete groups of four (< 16)
-                        const double *pa = a_src, *pb = b_src;
-                        int m = 0;
-                        for (; m + 4 <= ng; m += 4) {
-                            double av[4], bv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                av[u] = pa[4 * u];
-                                bv[u] = pb[4 * u];
-                            }
-                            pa += a_step;
-                            pb += b_step;
-#pragma unroll
-                            for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
-                        }
-                        for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
-                        if (left & 3) {
-                            // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
-                            const int u = ng & 3;
-                            const bool pad = mk >= (left & 3);
-                            const double av = pa[4 * u], bv = pb[4 * u];
-                            d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
-                        }
-                    }
-#ifdef PAGK_STAMPS
-                    asm volatile("" : "+v"(d));
-                    QSTAMP(2)
-#endif
-                    // ---- cost: ordered f32 sum, row q = feature q ----------------------------------------
-                    carry = chain_rows_f32<1>(sq_addr, 128u, 2);
-                }
+                carry = quad_chunk_phase(ops, P, c, sq_addr, d);  // H, b and cost of the chunk
                 __syncthreads();  // the chunk has been read before the next one is written
                 QSTAMP(3)
             }
@@ -313,15 +336,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             quad_acc(S)[mq][mk * 4 + mi] = d;
             __syncthreads();
             double H[4][4], b[4], upd[4];
-            {
-                const double *A = quad_acc(S)[row];
-                H[0][0] = A[0], H[1][0] = A[4], H[1][1] = A[5];
-                H[2][0] = A[8], H[2][1] = A[9], H[2][2] = A[11];
-                H[3][0] = A[12], H[3][1] = A[13];
-                H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
-                H[3][3] = (double)P;       // sum of 1.0*1.0
-                b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
-            }
+            quad_read_system(S, row, P, cd, H, b);
             float cost = carry;
             if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
             const double unorm = llt4_solve_norm(H, b, upd);

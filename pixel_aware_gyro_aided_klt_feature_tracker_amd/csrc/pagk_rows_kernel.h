@@ -40,11 +40,8 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
     auto first_of = [](unsigned long long m) { return (int)(__builtin_ctzll(m) >> 4); };
     auto without = [](unsigned long long m, int f) { return m & ~(0xffffull << (16 * f)); };
 
-    // MFMA operand roles of this lane: see k_track_quad
-    const int mk = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
-    const double *a_src = mi < 2 ? &S.chunk[mi][mq][mk] : (mi == 2 ? &S.cconst[mq][mk] : &S.ones[mk]);
-    const double *b_src = mi < 3 ? &S.chunk[mi][mq][mk] : &S.cconst[mq][mk];
-    const int a_step = mi < 2 ? 16 : 0, b_step = mi < 3 ? 16 : 0;  // doubles per four groups
+    const QuadOperands ops = quad_operands(S, lane);  // MFMA operand roles of this lane
+    const int mk = ops.mk, mq = ops.mq, mi = ops.mi;
     if (lane < 32) S.ones[lane] = 1.0;
     const uint32_t sq_addr = lds_off(&S.sq[row * 129]) + 8u * lr;
     float *ws = a.ws + (size_t)blockIdx.x * (4 * NCH * 64) + lane;  // img1 samples of the rows' current levels
@@ -218,57 +215,14 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
             }
             if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
             __syncthreads();
-            // ---- H, b and cost of the chunk.  A full chunk (64 pixels, 16 MFMA groups): one instruction stream in
-            // which the four DPP cost adds of a group sit between two dependent MFMAs (pagk_chain_asm.h:
-            // quad_chunk_full); the patch's last, shorter chunk: MFMA chain, then cost chain.
-            if (P - 64 * c >= 64) {
-                carry = quad_chunk_full(d, lds_off(a_src), lds_off(b_src), 8u * (uint32_t)a_step, 8u * (uint32_t)b_step, sq_addr);
-            } else {
-                // ---- H, b: one MFMA per four pixels, all four rows ---------------------------------------------
-                {
-                    const int left = P - 64 * c;                   // valid pixels from this chunk on
-                    const int ng = left >> 2;                      // complete groups of four (< 16)
-                    const double *pa = a_src, *pb = b_src;
-                    int m = 0;
-                    for (; m + 4 <= ng; m += 4) {
-                        double av[4], bv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            av[u] = pa[4 * u];
-                            bv[u] = pb[4 * u];
-                        }
-                        pa += a_step;
-                        pb += b_step;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], d, 0, 0, 0);
-                    }
-                    for (int u = 0; m < ng; m++, u++) d = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[4 * u], pb[4 * u], d, 0, 0, 0);
-                    if (left & 3) {
-                        // last, incomplete group: a pixel past the patch contributes fma(-0.0, 1.0, d) = d exactly
-                        const int u = ng & 3;
-                        const bool pad = mk >= (left & 3);
-                        const double av = pa[4 * u], bv = pb[4 * u];
-                        d = __builtin_amdgcn_mfma_f64_4x4x4f64(pad ? -0.0 : av, pad ? 1.0 : bv, d, 0, 0, 0);
-                    }
-                }
-                // ---- cost: ordered f32 sum, row q = feature of row q ---------------------------------------------
-                carry = chain_rows_f32<1>(sq_addr, 128u, 2);
-            }
+            carry = quad_chunk_phase(ops, P, c, sq_addr, d);  // H, b and cost of the chunk
             __syncthreads();  // the chunk has been read before the next one is written
         }
         // ---- solve (:302-319): D(q, i, j) sits in lane 16 i + 4 q + j; every lane of row q solves its feature
         quad_acc(S)[mq][mk * 4 + mi] = d;
         __syncthreads();
         double H[4][4], b[4], upd[4];
-        {
-            const double *A = quad_acc(S)[row];
-            H[0][0] = A[0], H[1][0] = A[4], H[1][1] = A[5];
-            H[2][0] = A[8], H[2][1] = A[9], H[2][2] = A[11];
-            H[3][0] = A[12], H[3][1] = A[13];
-            H[3][2] = (double)P * cd;  // sum of c*1.0: every partial sum k*c is exact
-            H[3][3] = (double)P;       // sum of 1.0*1.0
-            b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
-        }
+        quad_read_system(S, row, P, cd, H, b);
         float cost = carry;
         if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
         const double unorm = llt4_solve_norm(H, b, upd);
