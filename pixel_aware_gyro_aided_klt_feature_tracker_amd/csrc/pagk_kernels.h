@@ -564,22 +564,41 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
 
-    // accumulator row of this lane: entry id, its LDS stream, block stride
+    // accumulator row of this lane: its LDS stream, block stride.  A DPP row broadcasts ONE data value per step to its
+    // sixteen lanes, but the second FMA factor and the accumulator are per lane: entries that read the same stream
+    // with different constant factors share a row (H20 = sum Ix*c and H30 = sum Ix*1 in lanes 0 / 1 of the X row,
+    // likewise H21 | H31 and b2 | b3).  Eight rows = two waves carry the eleven data chains; the cost chain (f32) is
+    // wave 2; H22 = sum c*c depends on the level only and is chained once per level by wave 3.
+    //   row:      0    1    2    3    4    5          6          7         | 8-11  | 12-15
+    //   stream:   XX   YX   YY   XE   YE   X          Y          E         | esq   | cslot
+    //   entry:    H00  H10  H11  b0   b1   H20 | H30  H21 | H31  b2 | b3   | cost  | H22 (first iteration of a level)
+    // (the relaxed-order experiment keeps one row per entry: its lanes hold partial sums of ONE entry)
     const int lr = lane & 15;
     const int cid = wave * 4 + (lane >> 4);
-    // entry:        0    1    2    3    4    5    6    7    8    9    10   11(H22)
-    // stream:       XX   YX   YY   XE   YE   X    Y    X    Y    E    E    cslot
-    const int stream_of[12] = {0, 1, 2, 3, 4, 5, 6, 5, 6, 7, 7, 0};
+    const int stream_of[12] = {0, 1, 2, 3, 4, 5, 6, 5, 6, 7, 7, 0};  // relaxed-order experiment only
     uint32_t row_addr, row_inc;
-    if (MFMA || cid >= 12) {
-        row_addr = lds_off(esq) + 8u * lr;  // cost rows (MFMA variant: wave 1, all four rows)
-        row_inc = 128u;
-    } else if (cid < 11) {
-        row_addr = lds_off(stream + (size_t)stream_of[cid] * PS) + 16u * lr;
-        row_inc = 256u;
+    if constexpr (RELAXED || MFMA) {
+        if (MFMA || cid >= 12) {
+            row_addr = lds_off(esq) + 8u * lr;  // cost rows (MFMA variant: wave 1, all four rows)
+            row_inc = 128u;
+        } else if (cid < 11) {
+            row_addr = lds_off(stream + (size_t)stream_of[cid] * PS) + 16u * lr;
+            row_inc = 256u;
+        } else {
+            row_addr = lds_off(cslot);  // every lane re-reads (c, c)
+            row_inc = 0u;
+        }
     } else {
-        row_addr = lds_off(cslot);  // every lane re-reads (c, c)
-        row_inc = 0u;
+        if (cid < 8) {
+            row_addr = lds_off(stream + (size_t)cid * PS) + 16u * lr;
+            row_inc = 256u;
+        } else if (cid < 12) {
+            row_addr = lds_off(esq) + 8u * lr;
+            row_inc = 128u;
+        } else {
+            row_addr = lds_off(cslot);  // every lane re-reads (c, c)
+            row_inc = 0u;
+        }
     }
     // MFMA variant, operand roles of this lane: k = pixel within the group of four, q = block, i = row
     // (A) or column (B).  q = 0: A = B = J[i];  q = 1: A = J[i], B = (i == 0 ? -e : 0), i.e. b += J * (-e),
@@ -650,13 +669,22 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
         float s1[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) s1[r] = sample<true>(L1, ptx + px[r], pty + py[r]);
-        // second FMA factor of this lane's row (:264  J = (Ix, Iy, de_dg, 1))
+        // second FMA factor of this lane (:264  J = (Ix, Iy, de_dg, 1))
         double row_s1;
-        switch (cid) {
-            case 3: case 4: case 10: row_s1 = -1.0; break;  // b0 b1 b3:  -J * e
-            case 5: case 6: case 11: row_s1 = cd; break;     // H20 H21 H22
-            case 9: row_s1 = -cd; break;                     // b2
-            default: row_s1 = 1.0; break;
+        if constexpr (RELAXED) {
+            switch (cid) {
+                case 3: case 4: case 10: row_s1 = -1.0; break;  // b0 b1 b3:  -J * e
+                case 5: case 6: case 11: row_s1 = cd; break;     // H20 H21 H22
+                case 9: row_s1 = -cd; break;                     // b2
+                default: row_s1 = 1.0; break;
+            }
+        } else {
+            switch (cid) {
+                case 3: case 4: row_s1 = -1.0; break;                  // b0 b1:  -J * e
+                case 5: case 6: row_s1 = lr == 0 ? cd : 1.0; break;    // H20 | H30,  H21 | H31
+                case 7: row_s1 = lr == 0 ? -cd : -1.0; break;          // b2 | b3
+                default: row_s1 = cid >= 12 ? cd : 1.0; break;         // H22 (wave 3);  H00 H10 H11
+            }
         }
         if (tid == 0) {
             cslot[0] = cd;
@@ -823,12 +851,18 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                     float c = relaxed_row_f32(esq, P, lr);
                     if (lane == 15) sh_cost[0] = c;
                 }
-            } else if (wave < 3) {
+            } else if (wave < 2) {
                 double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
-                if (lr == 0) acc[cid] = s;
-            } else {
+                // slots as the solve reads them: H00 H10 H11 b0 b1 H20 H21 H30 H31 b2 b3 H22
+                if (lr == 0) acc[cid == 7 ? 9 : cid] = s;              // lane 0: H00 H10 H11 b0 | b1 H20 H21 b2
+                if (lr == 1 && cid >= 5) acc[cid == 7 ? 10 : cid + 2] = s;  // lane 1 of rows X Y E: H30 H31 b3
+            } else if (wave == 2) {
                 float c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
                 if (lane == 0) sh_cost[0] = c;
+            } else if (iter == iter_first) {
+                // H22 = the ordered sum of P copies of c*c: the same value in every iteration of this level
+                double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
+                if (lane == 0) acc[11] = s;
             }
             __syncthreads();
             STAMP(2)
