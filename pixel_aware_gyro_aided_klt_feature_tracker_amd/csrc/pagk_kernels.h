@@ -513,7 +513,10 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
+    // two-round patches: (NR, TAIL) determine the patch size (h = 8, 9, 10 <-> P mod 32 = 1, 9, 25), so every LDS
+    // address below is a compile-time constant (immediate offsets instead of address registers)
+    constexpr int HC = (NR == 2 && !MFMA) ? (TAIL == 1 ? 8 : (TAIL == 9 ? 9 : 10)) : 0;
+    const int h = HC ? HC : a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
     const int nfull = P / 32;  // P mod 32 == TAIL
 
     // array stride in doubles.  DPP variant: PP + 1, so that neighbouring streams start 8 bytes apart modulo the

@@ -24,7 +24,7 @@ for cfg, n, kern in cases:
 print("   ".join(out))
 ''' % ROOT
 libs = ["-"] + sys.argv[1:]
-for rep in range(3):
+for rep in range(int(os.environ.get("PAGK_AB_REPS", "3"))):
     for lib in libs:
         r = subprocess.run([sys.executable, "-c", child, lib], capture_output=True, text=True)
         print(("A (product) " if lib == "-" else "B (%s) " % os.path.basename(lib)) + r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
