@@ -66,7 +66,13 @@ typedef struct pagk_params {
     uint8_t calculate_ncc;            /* bCalculateNCC_                                   */
     uint8_t predict_method;           /* pagk_gyro_predict_device only: 0 or 1 = PIXEL_AWARE_PREDICTION, 2 =
                                          SINGLE_HOMOGRAPHY (ePredictMethod, include/gyro_aided_tracker.h:66-69)   */
-    uint8_t reserved0[1];
+    uint8_t solver_variant;           /* 0 = Eigen 3.3 with SSE2 packets, as restated in oracle/README.md.  Bits select
+                                         the association another Eigen version / build uses in H.llt().solve(b) and
+                                         update.norm() (src/patch_match.cpp:319,343):  1 lower solve row 3 as
+                                         (c0+c1)+c2;  2 upper solve row 0 as c0+(c1+c2);  4 squaredNorm sequential
+                                         (EIGEN_DONT_VECTORIZE);  8 LLT column scaling by the reciprocal (Eigen <= 3.2);
+                                         32 4th pivot's squaredNorm as a0+(a1+a2).  Same bits as
+                                         pagk_oracle_set_alternatives.  Others: PAGK_E_ARG.                         */
     float lambda;            /* mLambda      = 1.0f  (:48) */
     float alpha;             /* mAlpha       = 0.5f  (:49) */
     int32_t max_distance;    /* mMaxDistance = 25    (:50) */
@@ -232,6 +238,19 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
                      const double *pix_err, const double *dist_pred, const float *pt_pm,
                      const float *pt_pm_un, uint8_t *status_out, float *pt_predict,
                      float *pt_predict_un);
+
+/* Diagnostics (never on the tracking path): the arithmetic of H.llt().solve(b) / update.norm()
+ * (src/patch_match.cpp:319,343) on the caller's operands, so that a host can check on its own device -- and, with
+ * Eigen at hand, against its own Eigen -- what pagk_params::solver_variant selects.
+ * pagk_selftest_divide: per item i, q_plain[i] = num[i] / den[i] (the compiler's correctly rounded division),
+ * q_prepared[i] = the same quotient through the prepared-denominator form the kernels use, root[i] = sqrt(num[i]).
+ * pagk_selftest_solve: per 4x4 system (H row-major, lower triangle read; b) the update x and its norm from the
+ * one-lane form (x_serial, norm_serial = sqrt of the squared norm) and from the four-lane form (x_lanes, nsq_lanes =
+ * the squared norm the kernels compare with the threshold equivalent to `norm < 1e-2`).  Host pointers. */
+int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const double *den, double *q_plain,
+                         double *q_prepared, double *root);
+int pagk_selftest_solve(pagk_ctx *ctx, int32_t n, const double *H, const double *b, uint32_t solver_variant,
+                        double *x_serial, double *norm_serial, double *x_lanes, double *nsq_lanes);
 
 /* hipGraph capture of the per-frame work (BASELINE configs[4], "hipGraph-captured iterate").  A camera
  * stream issues the same launches on the same device pointers every frame; between pagk_graph_begin and

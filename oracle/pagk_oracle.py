@@ -48,6 +48,8 @@ def load():
         lib.pagk_oracle_log.argtypes = [C.c_double]
         lib.pagk_oracle_inv_log_max_dist.restype = C.c_float
         lib.pagk_oracle_inv_log_max_dist.argtypes = [C.c_float, i32]
+        lib.pagk_oracle_set_alternatives.restype = None
+        lib.pagk_oracle_set_alternatives.argtypes = [C.c_uint32]
         lib.pagk_oracle_llt_solve4.restype = C.c_double
         lib.pagk_oracle_llt_solve4.argtypes = [vp, vp, vp]
         f32 = C.c_float
@@ -135,6 +137,12 @@ def gyro_predict(cam_params: Params, width, height, half_patch, KRKinv, r3, pt_r
     if rc < 0:
         raise RuntimeError(f"pagk_oracle_gyro_predict: {rc}")
     return pu, pd, st, A
+
+
+def set_alternatives(flags: int) -> None:
+    """Switch the restatement's guesses about Eigen's associations (same bits as pagk_params::solver_variant; 16 = the
+    pyramid's fixed-point path).  Global: reset to 0 after use."""
+    load().pagk_oracle_set_alternatives(int(flags))
 
 
 def llt_solve4(H: np.ndarray, b: np.ndarray):

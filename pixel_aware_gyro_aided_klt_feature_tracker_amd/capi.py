@@ -34,7 +34,7 @@ class Params(C.Structure):
         ("has_gyro_predict_initial", C.c_uint8), ("inverse", C.c_uint8),
         ("consider_illumination", C.c_uint8), ("consider_affine", C.c_uint8),
         ("regularization_penalty", C.c_uint8), ("calculate_ncc", C.c_uint8),
-        ("predict_method", C.c_uint8), ("reserved0", C.c_uint8 * 1),
+        ("predict_method", C.c_uint8), ("solver_variant", C.c_uint8),
         ("lambda_", C.c_float), ("alpha", C.c_float), ("max_distance", C.c_int32),
         ("inv_log_max_dist", C.c_float),
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
@@ -49,7 +49,8 @@ class Outputs(C.Structure):
 
 
 def make_params(*, half_patch=5, iterations=10, pyramids=3, has_gyro=True, illumination=True,
-                affine=True, penalty=False, ncc=False, inverse=False, camera=None, predict_method=1) -> Params:
+                affine=True, penalty=False, ncc=False, inverse=False, camera=None, predict_method=1,
+                solver_variant=0) -> Params:
     """pagk_params_default() (reference call site src/gyro_aided_tracker.cpp:276-282)
     with overrides.  `camera` is a synth.Camera or None."""
     p = Params()
@@ -61,6 +62,7 @@ def make_params(*, half_patch=5, iterations=10, pyramids=3, has_gyro=True, illum
     p.regularization_penalty = int(penalty)
     p.calculate_ncc = int(ncc)
     p.predict_method = int(predict_method)   # 1 PIXEL_AWARE_PREDICTION, 2 SINGLE_HOMOGRAPHY (gyro prediction only)
+    p.solver_variant = int(solver_variant)   # Eigen association switches (include/pagk.h); 0 = Eigen 3.3 + SSE2
     p.lambda_, p.alpha, p.max_distance = 1.0, 0.5, 25
     p.inv_log_max_dist = 0.0
     if camera is not None:
@@ -198,6 +200,11 @@ def declare(lib) -> None:
                                              i32, i32, vp, vp, vp, vp]
     lib.pagk_ncc_free.restype = C.c_int
     lib.pagk_ncc_free.argtypes = [vp, _P(Image), _P(Image), i32, i32, vp, vp, vp, vp]
+    if hasattr(lib, "pagk_selftest_divide"):   # (absent from older builds that tools/ab_lib.py loads for A/B runs)
+        lib.pagk_selftest_divide.restype = C.c_int
+        lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        lib.pagk_selftest_solve.restype = C.c_int
+        lib.pagk_selftest_solve.argtypes = [vp, i32, vp, vp, C.c_uint32, vp, vp, vp, vp]
     lib.pagk_match_features.restype = C.c_int
     lib.pagk_match_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     # the sharded path
@@ -238,7 +245,7 @@ EXPORTED_SYMBOLS = [
     "pagk_near_neighbors_device", "pagk_find_near_neighbors", "pagk_ncc_free", "pagk_match_features",
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
-    "pagk_multi_allgather", "pagk_track_sharded",
+    "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
 ]
 
 
@@ -442,6 +449,26 @@ class Context:
         self._check(self.lib.pagk_ncc_free(self.h, C.byref(ir), C.byref(ic), half_patch, n, _ptr(pt_ref), _ptr(pt_cur),
                                            _ptr(affine), _ptr(out)), "pagk_ncc_free")
         return out[:n]
+
+    def selftest_divide(self, num: np.ndarray, den: np.ndarray):
+        """(num / den, the same through the prepared-denominator form, sqrt(num)) computed on the device."""
+        num, den = np.ascontiguousarray(num, np.float64), np.ascontiguousarray(den, np.float64)
+        n = int(num.shape[0])
+        qp, qq, rt = (np.zeros(max(n, 1), np.float64) for _ in range(3))
+        self._check(self.lib.pagk_selftest_divide(self.h, n, _ptr(num), _ptr(den), _ptr(qp), _ptr(qq), _ptr(rt)),
+                    "pagk_selftest_divide")
+        return qp[:n], qq[:n], rt[:n]
+
+    def selftest_solve(self, H: np.ndarray, b: np.ndarray, solver_variant: int = 0):
+        """H.llt().solve(b) and the update's norm for n 4x4 systems: (x, norm) of the one-lane form and
+        (x, squared norm) of the four-lane form."""
+        H, b = np.ascontiguousarray(H, np.float64), np.ascontiguousarray(b, np.float64)
+        n = int(H.shape[0])
+        xs, xl = np.zeros((max(n, 1), 4)), np.zeros((max(n, 1), 4))
+        ns, nl = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        self._check(self.lib.pagk_selftest_solve(self.h, n, _ptr(H), _ptr(b), int(solver_variant), _ptr(xs), _ptr(ns),
+                                                 _ptr(xl), _ptr(nl)), "pagk_selftest_solve")
+        return xs[:n], ns[:n], xl[:n], nl[:n]
 
     def gyro_predict_device_rot(self, params: Params, width: int, height: int, d_rot, n: int, d_pt_ref,
                                 d_pt_predict_un, d_pt_predict, d_status, d_affine):

@@ -74,6 +74,7 @@ struct TrackArgs {
     int *queue;
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
+    uint32_t solver;        // pagk_params::solver_variant (SV_* bits)
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)
     float lam_invlog_alpha; // mLambda * mInvLogMaxDist * mAlpha   (f32 product, :307)
     float alpha;
@@ -415,94 +416,206 @@ __device__ __forceinline__ double soft_log(double x)
 }
 
 // ---- H.llt().solve(b), update.norm()  (src/patch_match.cpp:319,343) -----------------------------
-// Operation order of Eigen 3.3's fixed-size 4x4 path (unblocked LLT that stops at a
-// non-positive pivot and leaves the rest of the matrix untouched, fully unrolled
-// triangular solves, SSE2-shaped squaredNorm).  M: lower triangle is read and overwritten.
-// Straight-line form (selects instead of the early return) so that the independent divides of a
-// column, and the forward substitution, can overlap: the f64 divide (~100 cycles) and sqrt (~146)
-// chains are what the solve costs.  `ok_k` = "column k was factorised": the reference returns at the
-// first pivot with x <= 0 (a NaN pivot does NOT stop it: `x <= 0` is false), leaving that column and
-// everything right of it untouched.  Values computed speculatively past a failed pivot are dropped by
-// the selects.
-__device__ __forceinline__ double llt4_solve_norm(double (&M)[4][4], const double (&b)[4], double (&x)[4])
+// Operation order of Eigen 3.3's fixed-size 4x4 path (unblocked LLT that stops at a non-positive pivot and leaves the
+// rest of the matrix untouched, fully unrolled triangular solves, SSE2-shaped squaredNorm).  That order is restated
+// from memory of a third-party library (oracle/README.md); the places where another Eigen version or build would
+// associate differently are switchable at run time -- pagk_params::solver_variant, the same bits as the oracle's
+// pagk_oracle_set_alternatives -- so that a host can make this library match ITS Eigen:
+enum : uint32_t {
+    SV_LOWER_SEQ = 1,   // lower solve, row 3: (c0 + c1) + c2 instead of c0 + (c1 + c2)
+    SV_UPPER_TREE = 2,  // upper solve, row 0: c0 + (c1 + c2) instead of (c0 + c1) + c2
+    SV_NORM_SEQ = 4,    // squaredNorm: ((x0^2 + x1^2) + x2^2) + x3^2 instead of the SSE2 packet shape
+    SV_LLT_RECIP = 8,   // Eigen <= 3.2: A21 *= 1/x instead of A21 /= x
+    SV_PIVOT_TREE = 32, // 4th pivot: A33 - (a0^2 + (a1^2 + a2^2)) instead of the sequential sum
+};
+
+// update.norm() < 1e-2 (:343) without the square root: sqrt is monotonic and correctly rounded, so
+// sqrt(s) < 0.01  <=>  s < T  with T the smallest double whose square root rounds to >= 0.01 (0x3f1a36e2eb1c432c;
+// tests/test_capi_cpu.py re-derives it with the host's correctly rounded sqrt, tests/test_parity_gpu.py checks the
+// device's sqrt on both sides of it).  NaN compares false in both forms.
+constexpr double kNormSqConverged = 0x1.a36e2eb1c432cp-14;
+
+// Division by a denominator that is used more than once.  hipcc expands an f64 `n / d` into v_div_scale x2, v_rcp_f64,
+// two Newton steps on the reciprocal, q0 = n * r, the residual fma(-d, q0, n), v_div_fmas and v_div_fixup: correctly
+// rounded.  For operands well inside the normal range the scale / fmas / fixup instructions are identities, so the
+// same instruction sequence can keep the refined reciprocal r(d) and spend three dependent FMAs per further numerator
+// -- bit for bit the compiler's quotient (tests/test_solver_gpu.py::test_division_by_prepared_denominator, 2^22
+// operand pairs incl. the range limits).  The solve runs in that form WITHOUT a branch per division: every division
+// records whether its operands were in range, and a solve in which one was not (zero, denormal, huge, inf, NaN: a
+// degenerate system) is repeated with plain divisions.
+struct Den {
+    double d, r;
+};
+// Exponent range of every operand of a solve's divisions, as ONE integer accumulator beside the dependent FMA chain
+// (a lone wave pays ~6 cycles per instruction of any kind, so the check is counted in instructions): per operand
+// t = (high word without sign) - (biased exponent 1023 - 400 in place), unsigned -- an exponent below the range wraps
+// to a huge t, one above it is large -- folded with v_max3_u32.  in_range(): every operand finite and normal with
+// 2^-400 <= |v| < 2^401.
+struct OperandRange {
+    static constexpr uint32_t kLow = (1023u - 400u) << 20, kSpan = (801u << 20) - 1u;
+    uint32_t t = 0u;
+    __device__ __forceinline__ void add(double v)
+    {
+        const uint32_t u = ((uint32_t)__double2hiint(v) & 0x7fffffffu) - kLow;
+        t = u > t ? u : t;
+    }
+    // a denominator: a negative one is out of range by definition (pivots and sums of squares are not negative)
+    __device__ __forceinline__ void add_positive(double v)
+    {
+        const uint32_t u = (uint32_t)__double2hiint(v) - kLow;
+        t = u > t ? u : t;
+    }
+    // a numerator that may be exactly +0.0 (see div_by): counted as in range
+    __device__ __forceinline__ void add_or_zero(double v)
+    {
+        uint32_t u = ((uint32_t)__double2hiint(v) & 0x7fffffffu) - kLow;
+        u = ((uint32_t)__double2hiint(v) | (uint32_t)__double2loint(v)) == 0u ? 0u : u;
+        t = u > t ? u : t;
+    }
+    __device__ __forceinline__ bool in_range() const { return t <= kSpan; }
+};
+template <bool FAST>
+__device__ __forceinline__ Den den_prepare(double d, OperandRange &rg)
+{
+    Den D;
+    D.d = d;
+    D.r = 0.0;
+    if constexpr (FAST) {
+        rg.add_positive(d);
+        double r = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-d, r, 1.0);
+        D.r = __builtin_fma(r, e, r);
+    }
+    return D;
+}
+// n / D.d; FAST: through the prepared reciprocal, `rg` collects the operands' exponents.  ZERO_OK: a numerator that is
+// exactly +0.0 counts as in range -- the three FMAs then return +-0 with the quotient's sign (-0.0 would not:
+// fma(+0, r, -0) = +0).  Used where a zero is an ordinary outcome: H is structurally singular, so the last row's
+// right-hand side b3 - sum is a difference of nearly equal numbers and cancels to +0 in a fair share of solves.
+template <bool FAST, bool ZERO_OK = false>
+__device__ __forceinline__ double div_by(double n, const Den &D, OperandRange &rg)
+{
+    if constexpr (FAST) {
+        if constexpr (ZERO_OK)
+            rg.add_or_zero(n);
+        else
+            rg.add(n);
+        const double q = n * D.r;
+        return __builtin_fma(__builtin_fma(-D.d, q, n), D.r, q);
+    } else {
+        return n / D.d;
+    }
+}
+// the checked single division (diagnostics: pagk_selftest_divide)
+__device__ __forceinline__ double div_one(double n, double d)
+{
+    OperandRange rg;
+    const double q = div_by<true>(n, den_prepare<true>(d, rg), rg);
+    return rg.in_range() ? q : n / d;
+}
+
+// The back substitution L^T x = y and the squared norm, shared by the two forms below.  D0..D3 hold the diagonal.
+template <bool FAST>
+__device__ __forceinline__ double llt4_upper_nsq(double r0, double r1, double r2, double r3, double L10, double L20,
+                                                 double L21, double L30, double L31, double L32, const Den &D0,
+                                                 const Den &D1, const Den &D2, const Den &D3, uint32_t sv,
+                                                 double (&x)[4], OperandRange &rg)
+{
+    r3 = div_by<FAST, true>(r3, D3, rg);
+    r2 -= L32 * r3;
+    r2 = div_by<FAST>(r2, D2, rg);
+    r1 -= L21 * r2 + L31 * r3;
+    r1 = div_by<FAST>(r1, D1, rg);
+    const double c0 = L10 * r1, c1 = L20 * r2, c2 = L30 * r3;
+    r0 -= (sv & SV_UPPER_TREE) ? c0 + (c1 + c2) : (c0 + c1) + c2;
+    r0 = div_by<FAST>(r0, D0, rg);
+    x[0] = r0;
+    x[1] = r1;
+    x[2] = r2;
+    x[3] = r3;
+    const double s0 = r0 * r0, s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
+    return (sv & SV_NORM_SEQ) ? ((s0 + s1) + s2) + s3 : (s0 + s2) + (s1 + s3);
+}
+
+// One lane solves one system.  M: lower triangle is read.  Returns update.squaredNorm() (compare with
+// kNormSqConverged).  `ok_k` = "column k was factorised": the reference returns at the first pivot with x <= 0 (a NaN
+// pivot does NOT stop it: `x <= 0` is false), leaving that column and everything right of it untouched; values
+// computed speculatively past a failed pivot are dropped by the selects.
+template <bool FAST>
+__device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], const double (&b)[4], double (&x)[4],
+                                                      uint32_t sv, OperandRange &rg)
 {
     const double H00 = M[0][0], H10 = M[1][0], H11 = M[1][1], H20 = M[2][0], H21 = M[2][1], H22 = M[2][2];
     const double H30 = M[3][0], H31 = M[3][1], H32 = M[3][2], H33 = M[3][3];
-    // `keep(v)`: an empty asm that pins a value in a VGPR, so the speculative sqrt / divides are
-    // evaluated unconditionally (the compiler otherwise turns `ok ? a / d : h` back into a branch,
-    // which splits the block and serialises the independent ~100-cycle divide chains).
-#define PAGK_KEEP(v) asm volatile("" : "+v"(v))
+    const bool recip = (sv & SV_LLT_RECIP) != 0;
+    // a column's scaling: A21 /= x (Eigen 3.3) or A21 *= 1/x (<= 3.2)
+    auto scale = [&](double n, const Den &D, double rx) { return recip ? n * rx : div_by<FAST>(n, D, rg); };
     // column 0
     const bool ok0 = !(H00 <= 0.0);
-    double sq0 = sqrt(H00);
-    PAGK_KEEP(sq0);
-    const double d0 = ok0 ? sq0 : H00;
-    double q10 = H10 / d0, q20 = H20 / d0, q30 = H30 / d0, r0 = b[0] / d0;
-    PAGK_KEEP(q10);
-    PAGK_KEEP(q20);
-    PAGK_KEEP(q30);
-    const double L10 = ok0 ? q10 : H10;
-    const double L20 = ok0 ? q20 : H20;
-    const double L30 = ok0 ? q30 : H30;
+    const double d0 = ok0 ? sqrt(H00) : H00;
+    const Den D0 = den_prepare<FAST>(d0, rg);
+    double rx = recip ? div_by<FAST>(1.0, D0, rg) : 0.0;
+    const double q10 = scale(H10, D0, rx), q20 = scale(H20, D0, rx), q30 = scale(H30, D0, rx);
+    const double r0 = div_by<FAST>(b[0], D0, rg);
+    const double L10 = ok0 ? q10 : H10, L20 = ok0 ? q20 : H20, L30 = ok0 ? q30 : H30;
     // column 1
     const double x1 = H11 - L10 * L10;
     const bool ok1 = ok0 && !(x1 <= 0.0);
-    double sq1 = sqrt(x1);
-    PAGK_KEEP(sq1);
-    const double d1 = ok1 ? sq1 : H11;
-    double q21 = (H21 - L20 * L10) / d1, q31 = (H31 - L30 * L10) / d1;
-    double r1 = (b[1] - L10 * r0) / d1;
-    PAGK_KEEP(q21);
-    PAGK_KEEP(q31);
-    const double L21 = ok1 ? q21 : H21;
-    const double L31 = ok1 ? q31 : H31;
+    const double d1 = ok1 ? sqrt(x1) : H11;
+    const Den D1 = den_prepare<FAST>(d1, rg);
+    rx = recip ? div_by<FAST>(1.0, D1, rg) : 0.0;
+    const double q21 = scale(H21 - L20 * L10, D1, rx), q31 = scale(H31 - L30 * L10, D1, rx);
+    const double r1 = div_by<FAST>(b[1] - L10 * r0, D1, rg);
+    const double L21 = ok1 ? q21 : H21, L31 = ok1 ? q31 : H31;
     // column 2
     double s = L20 * L20;
     s += L21 * L21;
     const double x2 = H22 - s;
     const bool ok2 = ok1 && !(x2 <= 0.0);
-    double sq2 = sqrt(x2);
-    PAGK_KEEP(sq2);
-    const double d2 = ok2 ? sq2 : H22;
+    const double d2 = ok2 ? sqrt(x2) : H22;
+    const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
-    double q32 = (H32 - s) / d2;
-    double r2 = (b[2] - (L20 * r0 + L21 * r1)) / d2;
-    PAGK_KEEP(q32);
+    rx = recip ? div_by<FAST>(1.0, D2, rg) : 0.0;
+    const double q32 = scale(H32 - s, D2, rx);
+    const double r2 = div_by<FAST>(b[2] - (L20 * r0 + L21 * r1), D2, rg);
     const double L32 = ok2 ? q32 : H32;
     // column 3
-    s = L30 * L30;
-    s += L31 * L31;
-    s += L32 * L32;
-    const double x3 = H33 - s;
+    const double a0 = L30 * L30, a1 = L31 * L31, a2 = L32 * L32;
+    const double x3 = H33 - ((sv & SV_PIVOT_TREE) ? a0 + (a1 + a2) : (a0 + a1) + a2);
     const bool ok3 = ok2 && !(x3 <= 0.0);
-    double sq3 = sqrt(x3);
-    PAGK_KEEP(sq3);
-    const double d3 = ok3 ? sq3 : H33;
-#undef PAGK_KEEP
-    // L y = b   (lower solve, interleaved above: r_i = (b_i - sum) / d_i with c0 + (c1 + c2) for the
-    // 3-term row) -- only r3 is left
-    double r3 = (b[3] - (L30 * r0 + (L31 * r1 + L32 * r2))) / d3;
-    // L^T x = y  (upper solve: (c0 + c1) + c2)
-    r3 /= d3;
-    r2 -= L32 * r3;
-    r2 /= d2;
-    r1 -= L21 * r2 + L31 * r3;
-    r1 /= d1;
-    r0 -= (L10 * r1 + L20 * r2) + L30 * r3;
-    r0 /= d0;
-    x[0] = r0;
-    x[1] = r1;
-    x[2] = r2;
-    x[3] = r3;
-    return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
+    const double d3 = ok3 ? sqrt(x3) : H33;
+    const Den D3 = den_prepare<FAST>(d3, rg);
+    // L y = b, last row (the rows above are interleaved with their columns): c0 + (c1 + c2)
+    const double c0 = L30 * r0, c1 = L31 * r1, c2 = L32 * r2;
+    const double r3 = div_by<FAST, true>(b[3] - ((sv & SV_LOWER_SEQ) ? (c0 + c1) + c2 : c0 + (c1 + c2)), D3, rg);
+    return llt4_upper_nsq<FAST>(r0, r1, r2, r3, L10, L20, L21, L30, L31, L32, D0, D1, D2, D3, sv, x, rg);
+}
+
+__device__ __forceinline__ double llt4_solve_nsq(const double (&M)[4][4], const double (&b)[4], double (&x)[4],
+                                                 uint32_t sv)
+{
+    OperandRange rg;
+    double nsq = llt4_solve_nsq_form<true>(M, b, x, sv, rg);
+    if (!rg.in_range()) nsq = llt4_solve_nsq_form<false>(M, b, x, sv, rg);  // a degenerate system: plain divisions
+    return nsq;
+}
+
+// The same with the square root taken (k_track_thread, the reference-shaped cross-check, tests `norm < 1e-2` as the
+// reference writes it: an on-device check of the threshold form the other kernels use) and plain divisions only.
+__device__ __forceinline__ double llt4_solve_norm(const double (&M)[4][4], const double (&b)[4], double (&x)[4],
+                                                  uint32_t sv)
+{
+    OperandRange rg;
+    return sqrt(llt4_solve_nsq_form<false>(M, b, x, sv, rg));
 }
 
 // The same solve spread over four lanes (l = 0..3 of one wave, all holding the same H and b): per
 // Cholesky column the divides of the rows below the pivot and the forward-substitution divide of that
-// column are ONE divide instruction executed by four lanes instead of up to four sequences in one lane;
-// results travel by v_readlane.  Operation for operation the arithmetic of llt4_solve_norm above (the
-// serial form stays in k_track_thread as the cross-check).  Critical path: 4 sqrt + 8 divides.
+// column are ONE divide executed by four lanes instead of up to four sequences in one lane;
+// results travel by v_readlane.  Operation for operation the arithmetic of llt4_solve_nsq_form above.
 __device__ __forceinline__ double lane_bcast(double v, int src)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -511,28 +624,41 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double llt4_solve_norm_lanes(const double (&M)[4][4], const double (&b)[4], int l,
-                                                        double (&x)[4])
+#ifdef PAGK_COUNT_REDO
+static __device__ uint32_t g_redo_lo, g_redo_hi;   // (diagnostic build: racy by design, last writer wins)
+#endif
+template <bool FAST>
+__device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4][4], const double (&b)[4], int l,
+                                                            double (&x)[4], uint32_t sv, OperandRange &rg)
 {
     const double H00 = M[0][0], H10 = M[1][0], H11 = M[1][1], H20 = M[2][0], H21 = M[2][1], H22 = M[2][2];
     const double H30 = M[3][0], H31 = M[3][1], H32 = M[3][2], H33 = M[3][3];
+    const bool recip = (sv & SV_LLT_RECIP) != 0;
+    // a column's scaling: n / d (Eigen 3.3) or n * (1 / d) (<= 3.2); `fwd`: this lane's quotient is the forward
+    // substitution's rhs[k] /= L(k,k), a true division in every version
+    auto column = [&](double n, const Den &D, bool fwd) {
+        const double q = div_by<FAST>(n, D, rg);
+        if (!recip) return q;
+        const double rx = div_by<FAST>(1.0, D, rg);
+        return fwd ? q : n * rx;
+    };
     // column 0: lane 0 -> r0 = b0 / d0, lane i -> L(i,0) = H(i,0) / d0
     const bool ok0 = !(H00 <= 0.0);
-    const double sq0 = sqrt(H00);
-    const double d0 = ok0 ? sq0 : H00;
+    const double d0 = ok0 ? sqrt(H00) : H00;
+    const Den D0 = den_prepare<FAST>(d0, rg);
     const double n0 = l == 0 ? b[0] : (l == 1 ? H10 : (l == 2 ? H20 : H30));
-    const double q0 = n0 / d0;
+    const double q0 = column(n0, D0, l == 0);
     const double own0 = (l == 0 || ok0) ? q0 : n0;
     double r0 = lane_bcast(own0, 0);
     const double L10 = lane_bcast(own0, 1), L20 = lane_bcast(own0, 2), L30 = lane_bcast(own0, 3);
     // column 1: lane 1 -> r1, lanes 2, 3 -> L(i,1)
     const double x1 = H11 - L10 * L10;
     const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double sq1 = sqrt(x1);
-    const double d1 = ok1 ? sq1 : H11;
+    const double d1 = ok1 ? sqrt(x1) : H11;
+    const Den D1 = den_prepare<FAST>(d1, rg);
     const double h1 = l == 2 ? H21 : H31;
     const double n1 = l == 1 ? b[1] - L10 * r0 : h1 - (l == 2 ? L20 : L30) * L10;
-    const double q1 = n1 / d1;
+    const double q1 = column(n1, D1, l == 1);
     const double own1 = (l == 1 || ok1) ? q1 : h1;
     double r1 = lane_bcast(own1, 1);
     const double L21 = lane_bcast(own1, 2), L31 = lane_bcast(own1, 3);
@@ -541,37 +667,41 @@ __device__ __forceinline__ double llt4_solve_norm_lanes(const double (&M)[4][4],
     s += L21 * L21;
     const double x2 = H22 - s;
     const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double sq2 = sqrt(x2);
-    const double d2 = ok2 ? sq2 : H22;
+    const double d2 = ok2 ? sqrt(x2) : H22;
+    const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
     const double n2 = l == 2 ? b[2] - (L20 * r0 + L21 * r1) : H32 - s;
-    const double q2 = n2 / d2;
+    const double q2 = column(n2, D2, l == 2);
     const double own2 = (l == 2 || ok2) ? q2 : H32;
     double r2 = lane_bcast(own2, 2);
     const double L32 = lane_bcast(own2, 3);
     // column 3
-    s = L30 * L30;
-    s += L31 * L31;
-    s += L32 * L32;
-    const double x3 = H33 - s;
+    const double a0 = L30 * L30, a1 = L31 * L31, a2 = L32 * L32;
+    const double x3 = H33 - ((sv & SV_PIVOT_TREE) ? a0 + (a1 + a2) : (a0 + a1) + a2);
     const bool ok3 = ok2 && !(x3 <= 0.0);
-    const double sq3 = sqrt(x3);
-    const double d3 = ok3 ? sq3 : H33;
-    double r3 = (b[3] - (L30 * r0 + (L31 * r1 + L32 * r2))) / d3;
+    const double d3 = ok3 ? sqrt(x3) : H33;
+    const Den D3 = den_prepare<FAST>(d3, rg);
+    const double c0 = L30 * r0, c1 = L31 * r1, c2 = L32 * r2;
+    const double r3 = div_by<FAST, true>(b[3] - ((sv & SV_LOWER_SEQ) ? (c0 + c1) + c2 : c0 + (c1 + c2)), D3, rg);
     // L^T x = y  (sequential by nature; every lane computes it)
-    r3 /= d3;
-    r2 -= L32 * r3;
-    r2 /= d2;
-    r1 -= L21 * r2 + L31 * r3;
-    r1 /= d1;
-    r0 -= (L10 * r1 + L20 * r2) + L30 * r3;
-    r0 /= d0;
-    x[0] = r0;
-    x[1] = r1;
-    x[2] = r2;
-    x[3] = r3;
-    return sqrt((r0 * r0 + r2 * r2) + (r1 * r1 + r3 * r3));
+    return llt4_upper_nsq<FAST>(r0, r1, r2, r3, L10, L20, L21, L30, L31, L32, D0, D1, D2, D3, sv, x, rg);
+}
+
+// (the calling lanes -- four, or a whole wave whose lanes 0..3 matter -- take the decision together: the form
+// broadcasts between them)
+__device__ __forceinline__ double llt4_solve_nsq_lanes(const double (&M)[4][4], const double (&b)[4], int l,
+                                                       double (&x)[4], uint32_t sv)
+{
+    OperandRange rg;
+    double nsq = llt4_solve_nsq_lanes_form<true>(M, b, l, x, sv, rg);
+#ifndef PAGK_EXPERIMENT_NO_REDO
+    if (__builtin_amdgcn_ballot_w64(!rg.in_range() && l < 4) != 0) nsq = llt4_solve_nsq_lanes_form<false>(M, b, l, x, sv, rg);
+#endif
+#ifdef PAGK_COUNT_REDO
+    g_redo_lo = rg.t;
+#endif
+    return nsq;
 }
 
 // Gyro regularisation penalty, src/patch_match.cpp:302-314.  Adds to H (lower triangle

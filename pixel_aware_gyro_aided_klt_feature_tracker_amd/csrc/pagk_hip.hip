@@ -250,6 +250,7 @@ int check_params(const pagk_params *p)
     if (p->half_patch < 1 || p->half_patch > PAGK_MAX_HALF_PATCH) return PAGK_E_ARG;
     if (p->iterations < 0 || p->pyramids < 1 || p->pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
     if (p->inverse) return PAGK_E_UNSUPPORTED;        // src/patch_match.cpp:220 "not support yet"
+    if (p->solver_variant & ~(SV_LOWER_SEQ | SV_UPPER_TREE | SV_NORM_SEQ | SV_LLT_RECIP | SV_PIVOT_TREE)) return PAGK_E_ARG;
     return PAGK_OK;
 }
 
@@ -321,7 +322,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.dist_pred = o->dist_pred;
     a.ncc = o->ncc;
     a.iters = o->iters;
-#ifdef PAGK_STAMPS
+#if defined(PAGK_STAMPS) || defined(PAGK_COUNT_REDO)
     a.dbg = reinterpret_cast<unsigned long long *>(getenv("PAGK_DBG_PTR") ? strtoull(getenv("PAGK_DBG_PTR"), nullptr, 0) : 0ull);
 #endif
     a.half = p->half_patch;
@@ -331,6 +332,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.use_affine = p->consider_affine;
     a.penalty = p->regularization_penalty;
     a.calc_ncc = p->calculate_ncc;
+    a.solver = p->solver_variant;
     float invlog = p->inv_log_max_dist != 0.0f ? p->inv_log_max_dist
                                                : pagk_inv_log_max_dist(p->alpha, p->max_distance);
     a.lam_invlog = p->lambda * invlog;           // :305  mLambda * mInvLogMaxDist (float)
@@ -1517,6 +1519,66 @@ int pagk_ncc_free(pagk_ctx *ctx, const pagk_image *ref, const pagk_image *cur, i
     } catch (const std::bad_alloc &) {
         return PAGK_E_NOMEM;
     }
+}
+
+// ---- diagnostics: the solve's arithmetic on arbitrary operands (pagk_selftest_kernel.h) --------------------------
+namespace {
+// n doubles-per-item arrays in, copied to the device as one block; returns device pointers through `d`
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const double *den, double *q_plain,
+                         double *q_prepared, double *root)
+{
+    if (!ctx || n < 0) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_selftest_divide");
+    if (n == 0) return PAGK_OK;
+    if (!num || !den || !q_plain || !q_prepared || !root) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch s;
+    const size_t nb = (size_t)n * sizeof(double);
+    HIPCHK(ctx, hipMalloc(&s.p, 5 * nb));
+    double *d = static_cast<double *>(s.p);
+    HIPCHK(ctx, hipMemcpyAsync(d, num, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d + n, den, nb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_divide, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d, d + n, d + 2 * (size_t)n,
+                       d + 3 * (size_t)n, d + 4 * (size_t)n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(q_plain, d + 2 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q_prepared, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(root, d + 4 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
+}
+
+int pagk_selftest_solve(pagk_ctx *ctx, int32_t n, const double *H, const double *b, uint32_t solver_variant,
+                        double *x_serial, double *norm_serial, double *x_lanes, double *nsq_lanes)
+{
+    if (!ctx || n < 0) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_selftest_solve");
+    if (solver_variant & ~(SV_LOWER_SEQ | SV_UPPER_TREE | SV_NORM_SEQ | SV_LLT_RECIP | SV_PIVOT_TREE)) return PAGK_E_ARG;
+    if (n == 0) return PAGK_OK;
+    if (!H || !b || !x_serial || !norm_serial || !x_lanes || !nsq_lanes) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch s;
+    const size_t nn = (size_t)n;
+    HIPCHK(ctx, hipMalloc(&s.p, (16 + 4 + 4 + 1 + 4 + 1) * nn * sizeof(double)));
+    double *dH = static_cast<double *>(s.p), *db = dH + 16 * nn, *dxs = db + 4 * nn, *dns = dxs + 4 * nn,
+           *dxl = dns + nn, *dnl = dxl + 4 * nn;
+    HIPCHK(ctx, hipMemcpyAsync(dH, H, 16 * nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(db, b, 4 * nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_solve, dim3((n + 15) / 16), dim3(64), 0, ctx->stream, n, dH, db, solver_variant, dxs, dns,
+                       dxl, dnl);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(x_serial, dxs, 4 * nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(norm_serial, dns, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(x_lanes, dxl, 4 * nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(nsq_lanes, dnl, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
 }
 
 // GyroAidedTracker::MatchFeatures, src/gyro_aided_tracker.cpp:949-1008.  Host-side: a sequential pass whose

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(64) k_track_thread(TrackArgs a)
                 }
             if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
             double upd[4];
-            double unorm = llt4_solve_norm(H, b, upd);  // :319
+            double unorm = llt4_solve_norm(H, b, upd, a.solver);  // :319
             if (upd[0] != upd[0]) {                     // :322
                 succ = 0;
                 break;
@@ -895,7 +895,25 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                 float cost = sh_cost[0];
                 if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
                 // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
-                double unorm = llt4_solve_norm_lanes(H, b, tid, upd);
+                double unorm = llt4_solve_nsq_lanes(H, b, tid, upd, a.solver);  // update.squaredNorm()
+#ifdef PAGK_COUNT_REDO
+                if (a.dbg) {
+                    OperandRange rg;
+                    double xx[4];
+                    llt4_solve_nsq_lanes_form<true>(H, b, tid, xx, a.solver, rg);
+                    if (tid == 0) {
+                        atomicAdd(a.dbg, 1ull);
+                        if (!rg.in_range()) {
+                            atomicAdd(a.dbg + 1, 1ull);
+                            a.dbg[4] = rg.t;
+                            for (int r = 0; r < 4; r++) {
+                                for (int c = 0; c <= r; c++) a.dbg[8 + r * 4 + c] = __double_as_longlong(H[r][c]);
+                                a.dbg[24 + r] = __double_as_longlong(b[r]);
+                            }
+                        }
+                    }
+                }
+#endif
                 if (tid == 0) {
                     sh_upd[0] = upd[0];
                     sh_upd[1] = upd[1];
@@ -924,7 +942,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             }
             lastCost = cost;  // :339
             succ = 1;
-            if (unorm < 1e-2) break;  // :343
+            if (unorm < kNormSqConverged) break;  // :343  update.norm() < 1e-2
 #ifdef PAGK_STAMPS
             asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dg), "+v"(db));
             STAMP(12)  // update read back, applied, termination tests
@@ -1109,3 +1127,4 @@ __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs
 #include "pagk_rows_kernel.h"
 #include "pagk_score_kernel.h"
 #include "pagk_neighbor_kernel.h"
+#include "pagk_selftest_kernel.h"

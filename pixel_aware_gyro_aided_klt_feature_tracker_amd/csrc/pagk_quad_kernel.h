@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             quad_read_system(S, row, P, cd, H, b);
             float cost = carry;
             if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
-            const double unorm = llt4_solve_norm(H, b, upd);
+            const double unorm = llt4_solve_nsq(H, b, upd, a.solver);  // update.squaredNorm()
             __syncthreads();  // the accumulators' LDS is the next iteration's first chunk
             // ---- update + termination (:322-344), per feature ------------------------------------------
             if (act) {
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     }
                     lastCost = cost;  // :339
                     succ = 1;
-                    if (unorm < 1e-2) act = false;  // :343
+                    if (unorm < kNormSqConverged) act = false;  // :343  update.norm() < 1e-2
                 }
             }
 #ifdef PAGK_STAMPS

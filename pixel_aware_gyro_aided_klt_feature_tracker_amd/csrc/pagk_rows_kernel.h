@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
         quad_read_system(S, row, P, cd, H, b);
         float cost = carry;
         if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
-        const double unorm = llt4_solve_norm(H, b, upd);
+        const double unorm = llt4_solve_nsq(H, b, upd, a.solver);  // update.squaredNorm()
         __syncthreads();  // the accumulators' LDS is the next iteration's first chunk
         // ---- update + termination (:322-344), then the row's next state -------------------------------------------
         if (act) {
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
                 }
                 lastCost = cost;  // :339
                 succ = 1;
-                if (unorm < 1e-2) cont = false;  // :343
+                if (unorm < kNormSqConverged) cont = false;  // :343  update.norm() < 1e-2
             }
             iter++;
             if (!cont || iter >= a.iterations) {  // the level is over (:215, :326, :330, :343)

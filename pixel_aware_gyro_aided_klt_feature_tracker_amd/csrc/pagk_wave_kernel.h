@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
                 float cost = sh_cost[0];
                 if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
                 // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
-                double unorm = llt4_solve_norm_lanes(H, b, lane, upd);
+                double unorm = llt4_solve_nsq_lanes(H, b, lane, upd, a.solver);  // update.squaredNorm()
                 if (lane == 0) {
                     sh_upd[0] = upd[0];
                     sh_upd[1] = upd[1];
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
             }
             lastCost = cost;
             succ = 1;
-            if (unorm < 1e-2) break;  // :343
+            if (unorm < kNormSqConverged) break;  // :343  update.norm() < 1e-2
         }
         p2x = ptx + dx;  // :348
         p2y = pty + dy;

@@ -127,3 +127,33 @@ def test_synth_is_deterministic():
     assert np.array_equal(a.img_cur, b.img_cur) and np.array_equal(a.pt_init, b.pt_init)
     assert np.array_equal(a.affine, b.affine)
     assert synth.SplitMix64(1).next_u64() == 0x910A2DEC89025CC1
+
+
+def test_norm_threshold_constant_is_the_image_of_one_hundredth():
+    """csrc/pagk_device.h: kNormSqConverged is the smallest double whose correctly rounded square root is >= 0.01, so
+    `update.squaredNorm() < kNormSqConverged` is `update.norm() < 1e-2` (reference src/patch_match.cpp:343)."""
+    import math
+    import re
+    import struct
+    src = open(os.path.join(ROOT, "pixel_aware_gyro_aided_klt_feature_tracker_amd", "csrc", "pagk_device.h")).read()
+    T = float.fromhex(re.search(r"kNormSqConverged = (0x[0-9a-fp.\-]+);", src).group(1))
+    below = struct.unpack("<d", struct.pack("<Q", struct.unpack("<Q", struct.pack("<d", T))[0] - 1))[0]
+    assert math.sqrt(T) >= 1e-2 and math.sqrt(below) < 1e-2   # math.sqrt is IEEE-correct
+
+
+def test_solver_variant_is_a_declared_parameter(built):
+    """include/pagk.h: the byte after predict_method; Python mirror at the same offset; oracle switch with the same bits."""
+    hdr = open(os.path.join(ROOT, "include", "pagk.h")).read()
+    assert "uint8_t solver_variant;" in hdr
+    assert capi.Params.solver_variant.offset == capi.Params.predict_method.offset + 1
+    from oracle import pagk_oracle as orc
+    import numpy as np
+    rng = np.random.default_rng(3)
+    J = rng.normal(0, 8, (441, 4)).astype(np.float32).astype(np.float64)
+    J[:, 2], J[:, 3] = -117.25, 1.0
+    H, b = J.T @ J, -J.T @ rng.normal(0, 5, 441)
+    x0, _ = orc.llt_solve4(H, b)
+    orc.set_alternatives(8)
+    x8, _ = orc.llt_solve4(H, b)
+    orc.set_alternatives(0)
+    assert not np.array_equal(x0, x8)   # the singular system amplifies the reciprocal scaling's last bit
