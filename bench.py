@@ -13,7 +13,10 @@ init; synthetic stand-in).  For N>1, `--scaling weak` (d
 N x 1000 keypoints on the same pair and `--scaling strong --config 3` the 1080p / 20000-keypoint
 pair of configs[3]; either way the keypoints are sharded in contiguous index blocks, one process
 per GPU, and every step ends with the RCCL all-gather of the per-rank (pt, status, err) slices.
-Rank 0 prints ONE JSON line.
+`--mode replicas --config 4` is BASELINE configs[4] as written: camera stream s lives on GPU s (the whole 1280x720 x
+4000-keypoint pair per GPU, the step a replayed hipGraph), no collective on the data path; the line's `value` is the
+aggregate over the N streams and `per_gpu_ms_per_step` lists each GPU's own step time.
+Rank 0 prints ONE JSON line; `config.mode` says which of the three forms (shard-weak, shard-strong, replicas) ran.
 """
 from __future__ import annotations
 
@@ -75,7 +78,13 @@ def measured_traffic(workload_name: str, n: int, kernel: str):
 
 
 KERNEL_OF_VARIANT = {0: "k_track_block", 1: "k_track_thread", 2: "k_track_block", 3: "k_track_wave", 4: "k_track_block",
-                     5: "k_track_quad"}
+                     5: "k_track_quad", 6: "k_track_rows"}
+
+
+def metric_label(w) -> str:
+    """BASELINE.json's metric with the workload's own patch / levels / iteration cap (configs[2] runs 4 levels)."""
+    side = 2 * w.half_patch + 1
+    return f"tracked features/sec ({side}x{side}, {w.pyramids}-lvl, {w.iterations} iter)"
 
 
 def spawn_ranks(n: int) -> int:
@@ -170,10 +179,15 @@ def config_row(cfg_idx: int, n: int, device: int, steps: int, streams: int = 1) 
     b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
     row = {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]}, {w.n} keypoints ({w.n_active} active), "
                        f"h={w.half_patch}, L={w.pyramids}, I={w.iterations}" + (f", {streams} concurrent streams" if streams > 1 else ""),
+           # ms_per_step = the faster of the two modes (named in step_mode); ms_per_step_graph is the headline's mode
            "ms_per_step": dt * 1e3, "features_per_s": w.n_active * streams / dt, "step_mode": step_mode,
+           "ms_per_step_graph": times["graph"] * 1e3, "features_per_s_graph": w.n_active * streams / times["graph"],
            "ms_per_step_by_mode": {k: v * 1e3 for k, v in times.items()},
            "mean_iters": float(it[w.status_in > 0].mean()), "max_iters": int(it.max()),
            "variant": capi.Context.VARIANT_NAMES.get(cams[0].ctx.last_variant(), "?"),
+           # features the throughput kernel handed to the latency kernel in the last direct launch (0: rule not applied;
+           # the hand-over never runs inside a replayed graph, so a row whose step_mode is "graph" did not use it)
+           "handover": int(cams[0].ctx.last_handover()),
            "kernel_ms": kms, "pyramid_ms": pms,
            "roofline_frac": w.n_active * b_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     for rt in cams:
@@ -187,14 +201,19 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--features-per-gpu", type=int, default=None, help="weak scaling: keypoints per GPU (default: the config's own count)")
-    ap.add_argument("--config", type=int, default=1, help="synth.config index (1 = BASELINE configs[1])")
+    ap.add_argument("--config", type=int, default=None, help="synth.config index (default 1 = BASELINE configs[1]; 4 with --mode replicas)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: N x the config's keypoints; strong: the config's keypoints split over N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config table and the side measurements")
-    ap.add_argument("--cameras", type=int, default=4, help="independent streams of the multi-camera side measurement")
+    ap.add_argument("--mode", choices=("shard", "replicas"), default="shard",
+                    help="shard: one frame pair, keypoints split over the GPUs + all-gather (--scaling weak|strong); "
+                         "replicas: an independent camera stream per GPU, no collective (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the CPU baseline sample")
     args = ap.parse_args()
+    replicas = args.mode == "replicas"
+    if args.config is None:
+        args.config = 4 if replicas else 1
 
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)   # before anything touches the GPU in this process
@@ -234,9 +253,10 @@ def main() -> int:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        want_capi = os.environ.get("PAGK_GATHER", "capi") == "capi"
+        # replicas: torch.distributed carries the barriers and the timing reduction only -- no data-path collective
+        want_capi = os.environ.get("PAGK_GATHER", "capi") == "capi" and not replicas
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        gather_via = "torch.distributed (RCCL backend)"
+        gather_via = "none (replicas)" if replicas else "torch.distributed (RCCL backend)"
         if want_capi:
             # Every rank must take the same branch (forming a communicator is itself a collective): each rank first
             # checks on its own that the library can reach RCCL at all (an id of its own costs nothing), the ranks
@@ -270,19 +290,30 @@ def main() -> int:
             if comm is None:
                 print(f"bench.py: library communicator unavailable on some rank ({why or 'another rank'}); gathering "
                       f"through torch.distributed", file=sys.stderr)
-    distributed.FORCE_COLLECTIVE = force_dist
+    distributed.FORCE_COLLECTIVE = force_dist and not replicas
 
     # identical inputs on every rank (seeded generator)
     per_gpu = args.features_per_gpu or NOMINAL_N[args.config]
-    n_total = NOMINAL_N[args.config] if args.scaling == "strong" else per_gpu * world
-    w = synth.config(args.config, n=n_total)
+    if replicas:
+        # one whole stream per GPU: every rank tracks all `per_gpu` keypoints of ITS frame pair (same shape, a seed
+        # of its own) and nothing is exchanged
+        n_total = per_gpu
+        w = synth.config(args.config, n=n_total, seed=0x5EED0000 + args.config + 0x100 * rank) if rank else \
+            synth.config(args.config, n=n_total)
+    else:
+        n_total = NOMINAL_N[args.config] if args.scaling == "strong" else per_gpu * world
+        w = synth.config(args.config, n=n_total)
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids,
                          has_gyro=w.has_gyro, camera=w.camera)
-    rt = runtime.ResidentTracker(p, device=local_rank, rank=rank, world=world)
+    rt = runtime.ResidentTracker(p, device=local_rank, rank=0 if replicas else rank, world=1 if replicas else world)
     rt.load_pair(w.img_ref, w.img_cur)
     rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
     n_active_total = w.n_active
     n_active_local = int(np.count_nonzero(w.status_in[rt.lo:rt.hi]))
+    if replicas and world > 1:
+        t = torch.tensor([w.n_active], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)   # (control plane: the aggregate's numerator)
+        n_active_total = int(t.item())
 
     def barrier():
         if world > 1:
@@ -293,8 +324,13 @@ def main() -> int:
     # PAGK_STEP_MODE=fused times the look-ahead form instead (needs frame k+1 while pair (k-1, k) is tracked).
     step_mode = os.environ.get("PAGK_STEP_MODE", "graph")
     elapsed, out = time_steps(rt, args.steps, args.warmup, step_mode, barrier)
+    per_gpu_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_gpu_ms = [float(v.item()) / args.steps * 1e3 for v in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     mode_used = rt.mode_used
@@ -304,7 +340,7 @@ def main() -> int:
     res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
     extras = {}
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and not replicas:
         # the collective by itself (events on the stream it runs on), and the same steps without it
         extras["gather"] = rt.gather_report(min(50, max(10, args.steps)))
         extras["gather"]["via"] = gather_via
@@ -347,30 +383,35 @@ def main() -> int:
         b_alg = algorithmic_bytes_per_feature(w.half_patch, w.pyramids)
         achieved = n_active_local * b_alg / (kernel_ms * 1e-3) / 1e9
         kname = KERNEL_OF_VARIANT.get(variant, "k_track_block")
-        traffic, traffic_tag = measured_traffic(w.name, n_total, kname) if world == 1 else (None, None)
+        traffic, traffic_tag = measured_traffic(w.name, n_total, kname) if world == 1 and not replicas else (None, None)
         P = (2 * w.half_patch + 1) ** 2
         it = res["iters"][:n_total]
         max_it = int(it.max())
         line = {
-            "metric": "tracked features/sec (21x21, 3-lvl, 30 iter)",
+            "metric": metric_label(w),
             "value": n_active_total * args.steps / elapsed,
             "unit": "features/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if replicas else args.scaling, "vs_baseline": None,
+            "per_gpu_ms_per_step": per_gpu_ms,
             "dtype": "f32 sampling, f64 normal equations", "data": "synthetic",
             "config": {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} pair, "
-                                   f"{n_total} keypoints ({n_total // world if args.scaling == 'strong' else per_gpu}/GPU), "
+                                   f"{n_total * world if replicas else n_total} keypoints "
+                                   f"({per_gpu if replicas or args.scaling != 'strong' else n_total // world}/GPU), "
                                    f"gyro-predicted affine init, h={w.half_patch}, L={w.pyramids}, I={w.iterations} "
                                    f"(synthetic stand-in for BASELINE configs[{args.config}])",
-                       "features_total": n_total, "features_active": n_active_total,
-                       "sharding": f"contiguous feature blocks x{world} + all-gather ({gather_via})" if world > 1 else "none",
+                       "mode": "replicas" if replicas else f"shard-{args.scaling}",
+                       "features_total": n_total * world if replicas else n_total, "features_active": n_active_total,
+                       "sharding": (f"none: {world} independent streams, one per GPU, no collective" if replicas else
+                                    f"contiguous feature blocks x{world} + all-gather ({gather_via})" if world > 1 else "none"),
                        "step": {"fused": "PatchMatch(all features of the pair) + pyramid(next frame) in ONE launch (trailing "
                                          "workgroups), replayed as a single-node hipGraph; needs one frame of look-ahead",
                                 "graph": "pyramid(current frame) -> PatchMatch(all features), replayed as one hipGraph launch; "
                                          "valid for a live camera"
                                 }.get(mode_used, f"pyramid + PatchMatch issued as direct launches ({mode_used})")
-                               + (" + all-gather of step k on a side stream, awaited before step k+1's tracking" if world > 1 else ""),
+                               + (" + all-gather of step k on a side stream, awaited before step k+1's tracking"
+                                  if world > 1 and not replicas else ""),
                        "step_mode": mode_used},
             # `bound` names the roofline the contract asks to price against; what actually binds the kernel is in
             # `binding_resource` (the fraction of HBM peak is tiny by construction: ~3.2 KB of compulsory bytes per

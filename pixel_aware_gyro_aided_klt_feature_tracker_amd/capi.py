@@ -584,8 +584,11 @@ class Multi:
 
     def __init__(self, devices=None, *, uid: bytes | None = None, rank: int = 0, world: int = 1, device: int = 0):
         self.lib = load()
+        self._lent = []   # Contexts handed out by ctx(): invalidated by close()
         h = C.c_void_p()
         if uid is None:
+            if devices is None or len(devices) == 0 or any(int(d) < 0 for d in devices):
+                raise ValueError("Multi(devices=[...]) needs a non-empty list of device indices (or uid=, rank=, world=)")
             devs = (C.c_int32 * len(devices))(*devices)
             rc = self.lib.pagk_multi_create(C.byref(h), devs, len(devices))
             where = "pagk_multi_create"
@@ -611,10 +614,14 @@ class Multi:
         return bytes(buf)
 
     def ctx(self, local_index: int = 0) -> Context:
+        if not getattr(self, "h", None):
+            raise RuntimeError("this Multi has been closed")
         p = self.lib.pagk_multi_ctx(self.h, local_index)
         if not p:
             raise IndexError(local_index)
-        return Context(_borrowed=p)
+        c = Context(_borrowed=p)
+        self._lent.append(c)
+        return c
 
     def _check(self, rc: int, where: str):
         if rc != PAGK_OK:
@@ -640,6 +647,9 @@ class Multi:
 
     def close(self):
         if getattr(self, "h", None):
+            for c in getattr(self, "_lent", []):
+                c.h = None    # the group owns its member contexts: a borrowed handle must not outlive it
+            self._lent = []
             self.lib.pagk_multi_destroy(self.h)
             self.h = None
 

@@ -16,6 +16,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <mutex>
+
 namespace {
 
 // the handful of RCCL entry points used, with the types of rccl.h restated (ncclComm_t is opaque, ncclResult_t
@@ -35,12 +37,8 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
-Rccl *rccl_load(char *err, size_t errn)
+void rccl_load_once(Rccl &r, char *err, size_t errn)
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
     const char *names[] = {getenv("PAGK_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *nm : names) {
         if (!nm || !*nm) continue;
@@ -49,7 +47,7 @@ Rccl *rccl_load(char *err, size_t errn)
     }
     if (!r.lib) {
         snprintf(err, errn, "cannot load librccl.so: %s", dlerror());
-        return nullptr;
+        return;
     }
     auto sym = [&](const char *n) { return dlsym(r.lib, n); };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -65,9 +63,20 @@ Rccl *rccl_load(char *err, size_t errn)
         snprintf(err, errn, "librccl.so lacks a required entry point");
         dlclose(r.lib);
         r.lib = nullptr;
-        return nullptr;
     }
-    return &r;
+}
+
+// Loaded once per process (std::call_once: contexts live on several host threads).  A failure is remembered WITH its
+// reason and every later call reports that reason again.
+Rccl *rccl_load(char *err, size_t errn)
+{
+    static Rccl r;
+    static char first_error[256] = {0};
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load_once(r, first_error, sizeof first_error); });
+    if (r.lib) return &r;
+    if (err && errn) snprintf(err, errn, "%s", first_error[0] ? first_error : "librccl.so could not be loaded");
+    return nullptr;
 }
 
 constexpr int kShardFields = 7;
@@ -217,7 +226,7 @@ int pagk_multi_create(pagk_multi **out, const int32_t *devices, int32_t n_device
 int pagk_multi_unique_id(uint8_t id[128])
 {
     if (!id) return PAGK_E_ARG;
-    char err[256];
+    char err[256] = {0};
     Rccl *r = rccl_load(err, sizeof err);
     if (!r) {
         fprintf(stderr, "pagk_multi_unique_id: %s\n", err);
@@ -307,6 +316,13 @@ int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_ima
     const size_t mm = (size_t)(m < 1 ? 1 : m);
     const size_t in_off[4] = {0, mm * 8, mm * 16, mm * 32};  // pt_ref | pt_init | affine | status_in
     const size_t in_bytes = mm * 33;
+    // (an error on member k leaves members 0 .. k-1 with launches in flight that read this call's staging: wait for them)
+    auto drain = [&](int upto) {
+        for (int j = 0; j < upto && j < G; j++) {
+            (void)hipSetDevice(pm->ctx[j]->device);
+            (void)hipStreamSynchronize(pm->ctx[j]->stream);
+        }
+    };
     // 1. every member: frames, pyramids, its block of the inputs, the tracking launch
     for (int k = 0; k < G; k++) {
         pagk_ctx *c = pm->ctx[k];
@@ -337,6 +353,7 @@ int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_ima
         }
         if ((rc = frame_upload_any(c, 4, ref, params->pyramids)) || (rc = frame_upload_any(c, 5, cur, params->pyramids))) {
             snprintf(pm->err, sizeof pm->err, "rank %d: %s", k, c->err);
+            drain(k);
             return rc;
         }
         int lo, hi;
@@ -364,6 +381,7 @@ int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_ima
                           affine ? reinterpret_cast<float *>(db + in_off[2]) : nullptr, db + in_off[3], &o);
         if (rc) {
             snprintf(pm->err, sizeof pm->err, "rank %d: %s", k, c->err);
+            drain(k);
             return rc;
         }
     }
@@ -371,7 +389,10 @@ int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_ima
     std::vector<const void *> snd((size_t)G);
     std::vector<void *> rcv((size_t)G);
     for (int k = 0; k < G; k++) snd[(size_t)k] = pm->stage[k].d_slice, rcv[(size_t)k] = pm->stage[k].d_all;
-    if ((rc = pagk_multi_allgather(pm, snd.data(), rcv.data(), slice, nullptr))) return rc;
+    if ((rc = pagk_multi_allgather(pm, snd.data(), rcv.data(), slice, nullptr))) {
+        drain(G);
+        return rc;
+    }
     // 3. member 0 hands the gathered slices to the host; everybody drains
     MHIPCHK(pm, hipSetDevice(pm->ctx[0]->device));
     MHIPCHK(pm, hipMemcpyAsync(pm->stage[0].h_all, pm->stage[0].d_all, slice * G, hipMemcpyDeviceToHost, pm->ctx[0]->stream));

@@ -225,7 +225,10 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
         quad_read_system(S, row, P, cd, H, b);
         float cost = carry;
         if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
-        const double unorm = llt4_solve_nsq(H, b, upd, a.solver);  // update.squaredNorm()
+        double unorm = 0.0;
+            // (rows without an iterating feature hold stale sums: they sit the solve out, so that only live systems can
+            // raise the exception flags that send the wave to the plain-division form)
+            if (act) unorm = llt4_solve_nsq(H, b, upd, a.solver);  // update.squaredNorm()
         __syncthreads();  // the accumulators' LDS is the next iteration's first chunk
         // ---- update + termination (:322-344), then the row's next state -------------------------------------------
         if (act) {

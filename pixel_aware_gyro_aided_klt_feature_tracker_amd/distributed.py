@@ -70,10 +70,25 @@ class Gathered:
 
     def __init__(self, raw: torch.Tensor, world: int, m: int, n: int, slice_bytes: int):
         self.raw, self.world, self.m, self.n, self.slice_bytes = raw, world, m, n, slice_bytes
+        # set by a caller that issued the collective on another stream than the reader's (runtime._sharded_step):
+        # `done` = the collective has written `raw`; `consumed` is recorded by unpack() so that the writer of the NEXT
+        # result into the same buffer can wait for this reader
+        self.done = None
+        self.consumed = None
 
     def unpack(self) -> dict:
+        """Full-length per-field tensors on the caller's current stream, ordered after the collective."""
+        if self.raw.is_cuda:
+            cur = torch.cuda.current_stream(self.raw.device)
+            if self.done is not None:
+                cur.wait_event(self.done)
         parts = [views_of(self.raw[r * self.slice_bytes:(r + 1) * self.slice_bytes], self.m) for r in range(self.world)]
-        return {name: torch.cat([p[name] for p in parts], dim=0)[:self.n] for name, _, _ in FIELDS}
+        out = {name: torch.cat([p[name] for p in parts], dim=0)[:self.n] for name, _, _ in FIELDS}
+        if self.raw.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.consumed = ev
+        return out
 
     # dict-like access so that callers can treat it as the unpacked result
     def items(self):

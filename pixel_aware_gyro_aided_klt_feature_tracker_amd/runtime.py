@@ -62,6 +62,12 @@ class ResidentTracker:
         self._drop_graph()
         self._settle()
 
+    def set_current_image(self, img_cur: np.ndarray):
+        """The next frame of the stream: new bytes into the SAME device buffer (captured graphs stay valid), ordered
+        on `main` after the launches that still read the old frame."""
+        with torch.cuda.stream(self.main):
+            self.img_cur.copy_(torch.from_numpy(np.ascontiguousarray(img_cur)).to(self.dev, non_blocking=False))
+
     def _settle(self):
         """Set-up work ran on torch's current stream and on `main`: let both finish before steps start."""
         torch.cuda.synchronize(self.dev)
@@ -227,14 +233,28 @@ class ResidentTracker:
                 self.mode_used = "serial"
             tracked = torch.cuda.Event()
             tracked.record(self.main)
+        # Two gather buffers, alternating: the result of step k stays intact while step k+1's gather runs, and a gather
+        # into a buffer waits for whoever unpacked the result that lived there (Gathered.consumed).
+        bufs = getattr(self, "_gather_bufs", None)
+        if bufs is None:
+            bufs = self._gather_bufs = [None, None]
+            self._gather_prev = [None, None]
+            self._gather_turn = 0
+        k = self._gather_turn
+        self._gather_turn = 1 - k
         with torch.cuda.stream(self.side):
             self.side.wait_event(tracked)
-            res = distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
-            if isinstance(res, distributed.Gathered):
-                self._gather_buf = res.raw
+            prev = self._gather_prev[k]
+            if prev is not None and prev.consumed is not None:
+                self.side.wait_event(prev.consumed)
+            res = distributed.all_gather_results(self.out, self.n, out=bufs[k])
             done = torch.cuda.Event()
             done.record(self.side)
             self._gather_done = done
+            if isinstance(res, distributed.Gathered):
+                bufs[k] = res.raw
+                res.done = done          # unpack() / to_numpy() on any stream wait for the collective
+                self._gather_prev[k] = res
         self._last_gather = res
         return res
 
@@ -251,7 +271,7 @@ class ResidentTracker:
             for _ in range(reps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.side)
-                distributed.all_gather_results(self.out, self.n, out=getattr(self, "_gather_buf", None))
+                distributed.all_gather_results(self.out, self.n, out=(getattr(self, "_gather_bufs", None) or [None])[0])
                 e1.record(self.side)
                 e1.synchronize()
                 ts.append(e0.elapsed_time(e1))

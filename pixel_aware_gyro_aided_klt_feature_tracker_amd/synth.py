@@ -240,7 +240,7 @@ def make_workload(name: str, width: int, height: int, n: int, *, seed: int, half
 
 # BASELINE.json `configs`, restated as synthetic stand-ins.
 def config(idx: int, n: int | None = None, **kw) -> Workload:
-    seed = 0x5EED0000 + idx
+    seed = kw.pop("seed", 0x5EED0000 + idx)   # (another seed = another stream of the same shape)
     if idx == 0:   # CPU plumbing: 640x480, 500 kpts, identity init, 21x21, 3 levels
         return make_workload("cfg0_640x480_identity", 640, 480, n or 500, seed=seed, motion="translation",
                              has_gyro=False, **kw)

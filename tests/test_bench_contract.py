@@ -92,3 +92,43 @@ def test_bench_forced_collective_reports_the_gather():
     g = b["gather"]
     assert g["gather_ms"] > 0 and g["ranks"] == 1 and "pagk_multi_allgather" in g["via"]
     assert g["ms_per_step_without_gather"] > 0 and b["value"] > 0
+
+
+def test_spawned_ranks_of_the_replicas_mode(monkeypatch):
+    """`bench.py --mode replicas --config 4 --gpus 8` (BASELINE configs[4]: one camera stream per GPU, no collective):
+    eight children with the same environment contract, the mode passed through; `--cameras` is gone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            seen.append((cmd, env, stdout))
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--mode", "replicas", "--config", "4"])
+    assert bench.spawn_ranks(8) == 0
+    assert [e["LOCAL_RANK"] for _, e, _ in seen] == [str(k) for k in range(8)] and {e["WORLD_SIZE"] for _, e, _ in seen} == {"8"}
+    assert all(c[-4:] == ["--mode", "replicas", "--config", "4"] for c, _, _ in seen)
+    monkeypatch.undo()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cameras", "4"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unrecognized arguments" in r.stderr
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "metric_label(w)" in src and '"(21x21, 3-lvl, 30 iter)"' not in src
+
+
+@pytest.mark.gpu
+def test_bench_replicas_mode_on_one_gpu():
+    """The replicas form with one rank: configs[4]'s stream shape, graph step, no collective, the mode named in the line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "replicas", "--steps", "6", "--warmup", "2",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert b["config"]["mode"] == "replicas" and b["config"]["features_total"] == 4000 and "gather" not in b
+    assert b["scaling"] == "weak" and len(b["per_gpu_ms_per_step"]) == 1 and b["config"]["step_mode"] == "graph"
+    assert "1280x720" in b["config"]["workload"] and b["metric"].startswith("tracked features/sec (21x21, 3-lvl, 30 iter)")

@@ -77,6 +77,60 @@ def test_frame_based_constructor_and_set_back_to_frame(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_frame_based_constructor_drives_patchmatch_on_the_gpu(built, tmp_path):
+    """tests/frame_ctor_gpu_test.cpp: the constructor both reference apps use (Examples/Demo/RealSenseD435i.cpp:244-254,
+    src/gyro_aided_tracker.cpp:30-49) with the apps' tracker type -> TrackFeatures() -> SetBackToFrame() (:97-111) on the
+    GPU: equal to the data constructor (checked inside the program) and to the oracle chain (checked here)."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = capi.PKG_DIR
+    exe = str(tmp_path / "frame_ctor_gpu_test")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), os.path.join(root, "tests", "frame_ctor_gpu_test.cpp"),
+                    "-o", exe, "-L", pkg, "-l:libpagk_tracker.so", "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    cam, w, _, K32 = _scene(n=300)
+    n = w.n
+    wv = -np.array((0.3, -0.4, 1.2)) + np.array((0.06, -0.04, 0.08))   # Rcl = dR^T; a gyro that is a little off
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", 320, 240, n))
+        f.write(w.img_ref.tobytes()); f.write(w.img_cur.tobytes()); f.write(w.pt_ref.astype(np.float32).tobytes())
+        f.write(struct.pack("<4f", cam.fx, cam.fy, cam.cx, cam.cy)); f.write(np.asarray(cam.dist[:4], np.float32).tobytes())
+        f.write(struct.pack("<3f", *wv)); f.write(struct.pack("<f", 0.05))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    raw = open(fout, "rb").read()
+    off = [4]
+
+    def take(dtype, count):
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off[0]).copy()
+        off[0] += a.nbytes
+        return a
+    assert struct.unpack_from("<i", raw, 0)[0] == n
+    st_in, pt_init, A = take(np.uint8, n), take(np.float32, 2 * n).reshape(n, 2), take(np.float32, 4 * n).reshape(n, 4)
+    st_pm, pt_pm = take(np.uint8, n), take(np.float32, 2 * n).reshape(n, 2)
+    pix_err, dist_pred = take(np.float64, n), take(np.float64, n)
+    st_frame, pt_frame = take(np.uint8, n), take(np.float32, 2 * n).reshape(n, 2)
+    survivors = struct.unpack_from("<i", raw, off[0])[0]
+    assert 0 < st_in.sum() < n or st_in.sum() == n
+    p = capi.make_params(half_patch=5, iterations=10, pyramids=3, has_gyro=True, illumination=True, affine=True,
+                         penalty=False, camera=cam)
+    ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, pt_init, A, st_in)
+    assert np.array_equal(st_pm, ref["status"][:n]) and np.array_equal(pt_pm, ref["pt_un"][:n])
+    assert np.array_equal(pix_err, ref["pix_err"][:n]) and np.array_equal(dist_pred, ref["dist_pred"][:n])
+    n_ok, st, pp, ppu = orc.post_filter(5, ref["status"][:n], ref["pix_err"][:n], ref["dist_pred"][:n],
+                                        ref["pt_dist"][:n], ref["pt_un"][:n])
+    assert survivors == n_ok and n_ok > n // 2 and np.array_equal(st_frame, st)
+    keep = st > 0
+    assert np.array_equal(pt_frame[keep], ref["pt_un"][:n][keep])     # what SetBackToFrame handed to the application
+    d = np.linalg.norm(pt_frame[keep].astype(np.float64) - w.pt_true[keep], axis=1)
+    assert np.median(d) < 0.1                                         # and the tracks are right, not just equal
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("type_", [2, 3, 4, 5, 6])
 def test_shell_track_features_end_to_end(built, type_):
     # the whole reference call stack for one frame pair, every eType, against the oracle chain

@@ -58,25 +58,40 @@ def test_runtime_gathers_through_the_c_abi_communicator(built):
     w = synth.config(1, n=600)
     p = params_for(w)
     g = capi.Multi([0])
+    # a different frame per step, and every result read WITHOUT a device-wide synchronisation in between: a reader of
+    # step()'s Gathered must be ordered after that step's collective (Gathered.done), and the next step's gather must
+    # not overwrite a result that is still being read (two buffers + Gathered.consumed)
+    frames = [w.img_cur, np.roll(w.img_cur, 1, axis=1).copy(), np.roll(w.img_cur, -1, axis=0).copy()]
     plain = runtime.ResidentTracker(p, device=0)
     plain.load_pair(w.img_ref, w.img_cur)
     plain.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
-    ref = distributed.to_numpy(plain.step())
-    plain.synchronize()
+    refs = []
+    for f in frames:
+        plain.set_current_image(f)
+        refs.append(distributed.to_numpy(plain.step()))
+        plain.synchronize()
+    assert not np.array_equal(refs[0]["pt_un"], refs[1]["pt_un"])
     distributed.COMM, distributed.FORCE_COLLECTIVE = g, True
+    gots = []
     try:
         rt = runtime.ResidentTracker(p, device=0)
         rt.load_pair(w.img_ref, w.img_cur)
         rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
-        for _ in range(3):
+        outs = []
+        for f in frames:
+            rt.set_current_image(f)
             out = rt.step()
-        assert isinstance(out, distributed.Gathered)
-        got = distributed.to_numpy(out)
+            assert isinstance(out, distributed.Gathered)
+            outs.append(out)
+            if len(outs) >= 2:      # read the PREVIOUS step's result while this step's gather is in flight
+                gots.append(distributed.to_numpy(outs[-2]))
+        gots.append(distributed.to_numpy(outs[-1]))
         rt.synchronize()
         rt.close()
     finally:
         distributed.COMM, distributed.FORCE_COLLECTIVE = None, False
         plain.close()
         g.close()
-    for k in ("pt_un", "pt_dist", "status", "pix_err", "dist_pred", "ncc", "iters"):
-        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    for got, ref in zip(gots, refs):
+        for k in ("pt_un", "pt_dist", "status", "pix_err", "dist_pred", "ncc", "iters"):
+            assert np.array_equal(got[k], ref[k], equal_nan=True), k
