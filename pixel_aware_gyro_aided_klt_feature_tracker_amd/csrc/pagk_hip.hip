@@ -50,6 +50,7 @@ struct pagk_ctx {
     void *quad_ws = nullptr;  // k_track_quad: iteration-invariant img1 samples, 4 * NCH * 64 floats per wave
     size_t quad_ws_bytes = 0;
     void *queue = nullptr;    // k_track_rows: the work-queue counter (256 B)
+    int quad_capacity[3] = {0, 0, 0};  // resident waves of k_track_quad<2 / 4 / 7> (occupancy x CUs): the hand-over rule's "round"
     int rows_capacity[3] = {0, 0, 0};  // resident waves of k_track_rows<2 / 4 / 7> on this device (occupancy x CUs)
     int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
@@ -274,18 +275,37 @@ void fill_level(DevLevel &d, const FrameSlot &s, int l)
 // tracking launch (k_track_block_pyr).  Honoured when the 4-wave kernel is the one selected; *pyr_done tells the
 // caller whether it was (otherwise the caller launches the pyramid itself).
 // Hand-over budget of a four-features-per-wave launch of `waves` wavefronts.  The hand-over pays where the launch ends
-// with an exposed tail -- between half a round and 1.25 rounds of resident waves (16 per CU): a handful of features
+// with an exposed tail -- between half a round and 1.25 rounds of resident waves (quad_capacity: the kernel's occupancy
+// on this device x its CU count; 16 x 256 on MI355X): a handful of features
 // with 3-5x the mean iteration count would otherwise each keep a wave alive long after the rest has finished
 // (configs[3], 20000 features: -6 %; 8000: -4 %).  With a fuller second round the first round's stragglers are already
 // hidden behind it and the finisher only displaces throughput waves (30000: +8 %), and a context that shares the device
 // (pagk_set_concurrency) has other launches to fill its tail.  profiles/r02_ab_runs.md.
-int quad_budget_for(const pagk_ctx *ctx, int waves, int iterations, int levels)
+// Resident waves of k_track_quad<NCH> on this device: the kernel's own occupancy (registers, its 10000 B of LDS) times
+// the CU count, asked once per context and patch size.
+int quad_capacity(pagk_ctx *ctx, int half)
+{
+    const int slot = half == 5 ? 0 : (half == 7 ? 1 : 2);
+    if (ctx->quad_capacity[slot] == 0) {
+        int per_cu = 0;
+        hipError_t e = half == 5   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_quad<2>, 64, 0)
+                       : half == 7 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_quad<4>, 64, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_quad<7>, 64, 0);
+        if (e != hipSuccess || per_cu <= 0) per_cu = 16;
+        ctx->quad_capacity[slot] = per_cu * (ctx->cus > 0 ? ctx->cus : 256);
+    }
+    return ctx->quad_capacity[slot];
+}
+
+int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int half)
 {
     if (ctx->quad_budget >= 0) return ctx->quad_budget;
     // a feature can run iterations x levels iterations at most: with the reference's own call site (10 x 3) nothing
     // runs long enough past the budget for the hand-over to pay for its list reset, finisher launch and sweep
     if (iterations * levels < 60) return 0;
-    const long long cap = 16ll * (ctx->cus > 0 ? ctx->cus : 256);
+    const long long cap = quad_capacity(ctx, half);  // one "round" of resident waves
+    // (beyond 1.25 rounds it loses, also when restricted to the launch's drain phase -- "a feature may leave only once
+    // every wave has been dispatched": +8 % at 30000 features, +5 % at 60000, profiles/r03_finisher_sweep_drain_rule.log)
     const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
     // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
     // finisher that starts after the throughput kernel is the plain sweep: +13 %)
@@ -419,7 +439,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             }
             a.ws = static_cast<float *>(ctx->quad_ws);
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
-            const int budget = quad_budget_for(ctx, (n + 3) / 4, p->iterations, p->pyramids);
+            const int budget = quad_budget_for(ctx, (n + 3) / 4, p->iterations, p->pyramids, a.half);
             const bool handover = budget > 0;
             ctx->last_handover = handover;
             if (handover) {

@@ -122,7 +122,10 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
     __shared__ __attribute__((aligned(256))) QuadLds S;
     const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
-    const int h = a.half, Wd = 2 * h + 1, P = Wd * Wd;
+    // the kernel is instantiated per patch size (NCH = chunks of 64 pixels: 2 <-> h = 5, 4 <-> h = 7, 7 <-> h = 10): the
+    // patch geometry is a compile-time constant (divisions by the patch width, LDS addresses, chunk lengths)
+    constexpr int h = NCH == 7 ? 10 : (NCH == 4 ? 7 : 5), Wd = 2 * h + 1, P = Wd * Wd;
+    static_assert(NCH == 2 || NCH == 4 || NCH == 7, "instantiated for h = 5, 7, 10");
     const int raw = 4 * (int)blockIdx.x + row;
     const int fi = raw < a.n ? raw : a.n - 1;  // rows past the end shadow the last feature and write nothing
     const bool live = raw < a.n && a.status_in[fi] != 0;
