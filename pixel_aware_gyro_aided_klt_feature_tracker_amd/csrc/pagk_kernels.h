@@ -430,7 +430,11 @@ __host__ __device__ inline int track_block_pp(int half)
 __host__ __device__ inline size_t track_block_lds_bytes(int half)
 {
     size_t PP = (size_t)track_block_pp(half);
-    return kStreams * (PP + 1) * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;  // streams PP + 1 doubles apart
+    size_t bytes = kStreams * (PP + 1) * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;  // streams PP + 1 doubles apart
+#ifdef PAGK_EXPERIMENT_LDS_WINDOW
+    bytes += 32 * 32 * 4;  // the staged img2 window (experiment build only, see track_block_body)
+#endif
+    return bytes;
 }
 // MFMA variant: three f64 streams of PP + 8 (the +8 staggers the banks of neighbouring arrays),
 // X = Ix, Y = Iy, NE = -e, written per iteration, followed by a 16-double constant area
@@ -531,6 +535,9 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     double *acc = cslot + 2;
     double *sh_upd = acc + kAcc;
     float *sh_cost = reinterpret_cast<float *>(sh_upd + 5);
+#ifdef PAGK_EXPERIMENT_LDS_WINDOW
+    uint32_t *win = reinterpret_cast<uint32_t *>(sh_cost + 2);  // 32 x 32 quads of img2 around the patch (experiment)
+#endif
 
     const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
     float p2x = init[2 * i], p2y = init[2 * i + 1];
@@ -775,6 +782,48 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                 }
             }
             };
+#ifdef PAGK_EXPERIMENT_LDS_WINDOW
+            // EXPERIMENT (never the product; BASELINE.json's north_star prescribes "pyramid levels staged into LDS tiles"):
+            // the 32 x 32 quads of img2 that contain every tap of this iteration are staged in LDS with coalesced row
+            // loads, and the five samples per pixel read their quad with ds_read_b32 and unpack the bytes (the typed
+            // buffer load's free conversion is not available for LDS).  Same arithmetic, same bits; measured against
+            // the product's gathers in profiles/r03_lds_window_experiment.log.
+            bool staged = false;
+            if constexpr (NR == 2 && !MFMA) {
+                if (interior && ext_x <= 14.0f && ext_y <= 14.0f) {   // (block-uniform)
+                    const int ox = (int)(bx - ext_x), oy = (int)(by - ext_y);
+                    for (int k = tid; k < 32 * 32; k += kBlock) {
+                        const int r = oy + (k >> 5), c = ox + (k & 31);
+                        win[k] = (r < L2.rows && c < L2.cols) ? L2.quad[(uint32_t)(__mul24(r, L2.cols) + c)] : 0u;
+                    }
+                    __syncthreads();
+                    auto tap = [&](float X, float Y) {
+                        const Coord cx = prep_coord<false>(X, L2.fcols, L2.fcols_m1), cy = prep_coord<false>(Y, L2.frows, L2.frows_m1);
+                        return bilerp(win[((cy.i - oy) << 5) + (cx.i - ox)], cx, cy);
+                    };
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const float X = bx + wx[r], Y = by + wy[r];
+                        Five sv;
+                        sv.c = tap(X, Y), sv.xp = tap(X + 1.0f, Y), sv.xm = tap(X - 1.0f, Y);
+                        sv.yp = tap(X, Y + 1.0f), sv.ym = tap(X, Y - 1.0f);
+                        const int p = tid + kBlock * r;
+                        if (p < P) {
+                            float e = sv.c + db - gain * s1[r];
+                            float Ix = 0.5f * (sv.xp - sv.xm), Iy = 0.5f * (sv.yp - sv.ym);
+                            double dIx = (double)Ix, dIy = (double)Iy, de = (double)e;
+                            stream[0 * PS + p] = dIx * dIx, stream[1 * PS + p] = dIy * dIx, stream[2 * PS + p] = dIy * dIy;
+                            stream[3 * PS + p] = dIx * de, stream[4 * PS + p] = dIy * de;
+                            stream[5 * PS + p] = dIx, stream[6 * PS + p] = dIy, stream[7 * PS + p] = de;
+                            esq[p] = e * e;
+                        }
+                    }
+                    staged = true;
+                }
+            }
+            if (staged) {
+            } else
+#endif
             if constexpr (MFMA)
                 sampling(std::integral_constant<int, 2>{});
             else if (interior)

@@ -909,3 +909,24 @@ def test_resident_tracker_step_modes_agree(ctx):
         assert rt.mode_used == mode
         assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what=f"step mode {mode}")
     rt.close()
+
+
+def test_live_step_with_the_frame_copied_from_pinned_memory(ctx):
+    """ResidentTracker.step_live: host (pinned) -> device copy on a copy stream, two alternating buffers, graph replay
+    waiting for the copy: same results as the resident step, for alternating frames."""
+    w = synth.config(1, n=300)
+    p = params_for(w)
+    frames = [w.img_cur, np.roll(w.img_cur, 2, axis=1).copy(), np.roll(w.img_cur, -1, axis=0).copy(), w.img_cur]
+    rt = runtime.ResidentTracker(p, device=0)
+    rt.load_pair(w.img_ref, w.img_cur)
+    rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+    try:
+        for f in frames:
+            pinned = torch.from_numpy(np.ascontiguousarray(f)).pin_memory()
+            out = rt.step_live(pinned)
+            rt.synchronize()
+            got = distributed.to_numpy(out)
+            ref = orc.track(p, w.img_ref, f, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
+            assert_parity(got, ref, w.n, exact=True, what="live step")
+    finally:
+        rt.close()
