@@ -356,8 +356,8 @@ def main() -> int:
         extras["step_modes_ms"] = modes
         extras["step_modes_note"] = ("graph = value's mode (valid for a live camera); fused = PatchMatch + the NEXT frame's pyramid "
                                      "in one launch (needs one frame of look-ahead)")
-        # the live-camera step including the frame's host -> device copy (pinned memory, copy stream, overlapped with the
-        # previous frame's tracking): what `value` leaves out by starting with the frame resident
+        # the live-camera step including the frame's host -> device copy (pinned memory): what `value` leaves out by
+        # starting with the frame resident
         pinned = torch.from_numpy(np.ascontiguousarray(w.img_cur)).pin_memory()
         for _ in range(6):
             rt.step_live(pinned)
@@ -368,9 +368,9 @@ def main() -> int:
         torch.cuda.synchronize()
         tl = (time.perf_counter() - t1) / ksteps
         extras["live_step"] = {"ms_per_step": tl * 1e3, "value": n_active_total / tl, "unit": "features/s",
-                               "what": f"per frame: {w.img_cur.nbytes} B host (pinned) -> device on a copy stream, two "
-                                       "alternating device buffers, then pyramid -> PatchMatch replayed as a hipGraph that "
-                                       "waits for the copy; the copy of frame k+1 overlaps the tracking of frame k"}
+                               "what": f"per frame: {w.img_cur.nbytes} B host (pinned) -> device, pyramid, PatchMatch as ONE "
+                                       "replayed hipGraph (pagk_frame_upload_pinned is capturable): the step of a live "
+                                       "camera loop with the frame's PCIe transfer inside"}
         # (a) the drop-in call itself: pagk_track on HOST buffers -- two frame uploads, pyramids, per-feature
         #     arrays in, results out, synchronous.  PCIe-inclusive; never `value`.
         hctx = capi.Context(local_rank)

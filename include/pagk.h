@@ -142,6 +142,11 @@ int pagk_track_pyr(pagk_ctx *ctx, const pagk_params *params, int32_t n_levels,
  * t+1, so each frame is uploaded once. slot in [0, 4).  Returns after img->data has been read (the caller may
  * reuse the buffer at once, also when it is pinned memory); the pyramid kernels may still be running. */
 int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids);
+/* The same for a frame in PINNED host memory (a camera ring buffer): asynchronous on the context's stream and
+ * capturable -- inside pagk_graph_begin / pagk_graph_end the host -> device copy becomes a graph node, so a live loop
+ * (Examples/Demo/RealSenseD435i.cpp:199-321: grab, track) replays [copy the frame -> pyramid -> PatchMatch] with one
+ * pagk_graph_launch per frame.  The memory must stay pinned, and unchanged until the enqueued work has run. */
+int pagk_frame_upload_pinned(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids);
 /* Same for an image that already lives in device memory (d_data: device pointer,
  * rows of `step` bytes). Asynchronous on the context stream. */
 int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width,

@@ -145,6 +145,8 @@ def declare(lib) -> None:
     lib.pagk_track_pyr.argtypes = [vp, _P(Params), i32, _P(Image), _P(Image), i32, vp, vp, vp, vp, _P(Outputs)]
     lib.pagk_frame_upload.restype = C.c_int
     lib.pagk_frame_upload.argtypes = [vp, i32, _P(Image), i32]
+    lib.pagk_frame_upload_pinned.restype = C.c_int
+    lib.pagk_frame_upload_pinned.argtypes = [vp, i32, _P(Image), i32]
     lib.pagk_frame_set_device.restype = C.c_int
     lib.pagk_frame_set_device.argtypes = [vp, i32, vp, i32, i32, C.c_int64, i32]
     lib.pagk_frame_download_level.restype = C.c_int
@@ -236,7 +238,7 @@ def declare(lib) -> None:
 
 EXPORTED_SYMBOLS = [
     "pagk_version", "pagk_strerror", "pagk_last_error", "pagk_params_default", "pagk_inv_log_max_dist",
-    "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload",
+    "pagk_create", "pagk_destroy", "pagk_track", "pagk_track_pyr", "pagk_frame_upload", "pagk_frame_upload_pinned",
     "pagk_frame_set_device", "pagk_frame_download_level", "pagk_track_device", "pagk_track_device_fused", "pagk_sync",
     "pagk_set_stream", "pagk_set_kernel", "pagk_last_variant", "pagk_set_concurrency", "pagk_last_handover", "pagk_last_kernel_ms", "pagk_post_filter", "pagk_gyro_predict_device",
     "pagk_gyro_predict_device_rot",
@@ -326,6 +328,11 @@ class Context:
     def frame_upload(self, slot: int, img: np.ndarray, pyramids: int):
         iv = image_view(img)
         self._check(self.lib.pagk_frame_upload(self.h, slot, C.byref(iv), pyramids), "pagk_frame_upload")
+
+    def frame_upload_pinned(self, slot: int, host_ptr: int, width: int, height: int, step: int, pyramids: int):
+        """pagk_frame_upload_pinned: asynchronous / capturable upload of a frame that lives in pinned host memory."""
+        iv = Image(host_ptr, width, height, step)
+        self._check(self.lib.pagk_frame_upload_pinned(self.h, slot, C.byref(iv), pyramids), "pagk_frame_upload_pinned")
 
     def frame_set_device(self, slot: int, d_ptr: int, width: int, height: int, step: int, pyramids: int):
         self._check(self.lib.pagk_frame_set_device(self.h, slot, d_ptr, width, height, step, pyramids),

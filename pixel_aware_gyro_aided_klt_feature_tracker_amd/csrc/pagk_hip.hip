@@ -917,6 +917,17 @@ int pagk_frame_upload(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_
     return PAGK_OK;
 }
 
+// The same for a frame in PINNED host memory (a camera driver's ring buffer, hipHostMalloc / hipHostRegister):
+// asynchronous -- returns once the copy and the pyramid are enqueued on the context's stream -- and capturable: between
+// pagk_graph_begin and pagk_graph_end the host -> device copy becomes a node of the graph, so a live loop replays
+// [copy the frame the camera just wrote -> pyramid -> PatchMatch] with one pagk_graph_launch per frame.  The caller
+// keeps the memory pinned, and unchanged from the call (or the replay) until that work has run.
+int pagk_frame_upload_pinned(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
+{
+    if (!ctx || slot < 0 || slot >= kUserSlots) return PAGK_E_ARG;
+    return frame_upload_any(ctx, slot, img, pyramids);
+}
+
 static int frame_upload_any(pagk_ctx *ctx, int32_t slot, const pagk_image *img, int32_t pyramids)
 {
     if (!ctx || slot < 0 || slot >= kSlots || pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;

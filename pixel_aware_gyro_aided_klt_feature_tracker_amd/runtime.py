@@ -77,11 +77,9 @@ class ResidentTracker:
             for gid in ids:
                 self.ctx.graph_destroy(gid)
         self._graphs = {}
-        if hasattr(self, "_live"):
-            for gid in self._live["graphs"]:
-                if gid is not None:
-                    self.ctx.graph_destroy(gid)
-            del self._live
+        if getattr(self, "_live", None) is not None:
+            self.ctx.graph_destroy(self._live[1])
+            self._live = None
 
     @property
     def _graph(self):
@@ -264,45 +262,32 @@ class ResidentTracker:
         return res
 
     def step_live(self, host_frame: "torch.Tensor"):
-        """The step of a live camera loop INCLUDING the frame's way onto the device: `host_frame` (pinned uint8, h x w)
-        is copied host -> device on a copy stream into one of two alternating device buffers, the pyramid + PatchMatch
-        graph that reads that buffer waits for the copy and is replayed on `main`.  The copy of frame k+1 overlaps the
-        tracking of frame k; nothing is synchronised with the host.  (Examples/Demo/RealSenseD435i.cpp:199-321 is the
-        loop this stands for: grab, convert, track.)"""
-        if not hasattr(self, "_live"):
-            self._live = {"bufs": [torch.empty_like(self.img_cur), torch.empty_like(self.img_cur)], "turn": 0,
-                          "copy": torch.cuda.Stream(device=self.dev), "graphs": [None, None], "used": [None, None]}
-            for k in (0, 1):   # warm-up + capture: [pyramid(slot 1 <- buffer k) -> PatchMatch(0, 1)]
-                buf = self._live["bufs"][k]
-                buf.copy_(self.img_cur)
-                torch.cuda.synchronize(self.dev)
-                with torch.cuda.stream(self.main):
-                    self.ctx.frame_set_device(1, buf.data_ptr(), self.w, self.h, self.w, self.params.pyramids)
+        """The step of a live camera loop INCLUDING the frame's way onto the device: `host_frame` is the camera's PINNED
+        uint8 buffer (h x w); the graph [host -> device copy of that buffer -> pyramid -> PatchMatch] is captured on
+        first use (pagk_frame_upload_pinned is capturable) and replayed with one launch per frame -- the caller writes
+        the new frame into the same pinned buffer before each call.  (Examples/Demo/RealSenseD435i.cpp:199-321 is the
+        loop this stands for: grab, convert, track.)  Returns the rank's device outputs; nothing is synchronised."""
+        key = (host_frame.data_ptr(), tuple(host_frame.shape))
+        if getattr(self, "_live", None) is None or self._live[0] != key:
+            if getattr(self, "_live", None) is not None:
+                self.ctx.graph_destroy(self._live[1])
+            if not host_frame.is_pinned():
+                raise ValueError("step_live needs the frame in pinned host memory")
+            h, w = host_frame.shape
+            with torch.cuda.stream(self.main):
+                self.ctx.frame_upload_pinned(1, host_frame.data_ptr(), w, h, host_frame.stride(0), self.params.pyramids)
+                self.track_shard(1)                      # warm-up: allocations, kernel attributes
+                self.main.synchronize()
+                self.ctx.graph_begin()
+                try:
+                    self.ctx.frame_upload_pinned(1, host_frame.data_ptr(), w, h, host_frame.stride(0), self.params.pyramids)
                     self.track_shard(1)
-                    self.main.synchronize()
-                    self.ctx.graph_begin()
-                    try:
-                        self.ctx.frame_set_device(1, buf.data_ptr(), self.w, self.h, self.w, self.params.pyramids)
-                        self.track_shard(1)
-                    finally:
-                        self._live["graphs"][k] = self.ctx.graph_end()
-        L = self._live
-        k = L["turn"]
-        L["turn"] = 1 - k
-        with torch.cuda.stream(L["copy"]):
-            if L["used"][k] is not None:
-                L["copy"].wait_event(L["used"][k])      # the graph that last read this buffer has finished
-            L["bufs"][k].copy_(host_frame, non_blocking=True)
-            arrived = torch.cuda.Event()
-            arrived.record(L["copy"])
-        with torch.cuda.stream(self.main):
-            self.main.wait_event(arrived)
-            self.ctx.graph_launch(L["graphs"][k])
-            used = torch.cuda.Event()
-            used.record(self.main)
-            L["used"][k] = used
+                finally:
+                    gid = self.ctx.graph_end()
+            self._live = (key, gid, host_frame)          # (keeps the pinned buffer alive as long as the graph)
+        self.ctx.graph_launch(self._live[1])
         self.mode_used = "live"
-        return {name: self.out[name][:self.hi - self.lo] for name, _, _ in distributed.FIELDS}
+        return self.out
 
     def finish(self):
         """Order everything issued so far (tracking on `main`, the last gather on `side`) before the caller's

@@ -912,8 +912,9 @@ def test_resident_tracker_step_modes_agree(ctx):
 
 
 def test_live_step_with_the_frame_copied_from_pinned_memory(ctx):
-    """ResidentTracker.step_live: host (pinned) -> device copy on a copy stream, two alternating buffers, graph replay
-    waiting for the copy: same results as the resident step, for alternating frames."""
+    """ResidentTracker.step_live: [host (pinned) -> device copy, pyramid, PatchMatch] captured once (the copy is a node
+    of the graph: pagk_frame_upload_pinned) and replayed per frame after the host rewrote the pinned buffer: same
+    results as the oracle on every frame; pageable memory is refused."""
     w = synth.config(1, n=300)
     p = params_for(w)
     frames = [w.img_cur, np.roll(w.img_cur, 2, axis=1).copy(), np.roll(w.img_cur, -1, axis=0).copy(), w.img_cur]
@@ -921,12 +922,15 @@ def test_live_step_with_the_frame_copied_from_pinned_memory(ctx):
     rt.load_pair(w.img_ref, w.img_cur)
     rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
     try:
+        pinned = torch.from_numpy(np.ascontiguousarray(w.img_cur)).pin_memory()
         for f in frames:
-            pinned = torch.from_numpy(np.ascontiguousarray(f)).pin_memory()
+            pinned.copy_(torch.from_numpy(np.ascontiguousarray(f)))      # the "camera" writes the next frame
             out = rt.step_live(pinned)
             rt.synchronize()
-            got = distributed.to_numpy(out)
+            got = distributed.to_numpy({name: out[name][:w.n] for name, _, _ in distributed.FIELDS})
             ref = orc.track(p, w.img_ref, f, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
             assert_parity(got, ref, w.n, exact=True, what="live step")
+        with pytest.raises(ValueError):
+            rt.step_live(torch.from_numpy(np.ascontiguousarray(w.img_cur)))
     finally:
         rt.close()
