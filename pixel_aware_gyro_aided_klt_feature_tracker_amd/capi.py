@@ -145,8 +145,9 @@ def declare(lib) -> None:
     lib.pagk_track_pyr.argtypes = [vp, _P(Params), i32, _P(Image), _P(Image), i32, vp, vp, vp, vp, _P(Outputs)]
     lib.pagk_frame_upload.restype = C.c_int
     lib.pagk_frame_upload.argtypes = [vp, i32, _P(Image), i32]
-    lib.pagk_frame_upload_pinned.restype = C.c_int
-    lib.pagk_frame_upload_pinned.argtypes = [vp, i32, _P(Image), i32]
+    if hasattr(lib, "pagk_frame_upload_pinned"):   # (absent from older builds that tools/ab_lib.py loads for A/B runs)
+        lib.pagk_frame_upload_pinned.restype = C.c_int
+        lib.pagk_frame_upload_pinned.argtypes = [vp, i32, _P(Image), i32]
     lib.pagk_frame_set_device.restype = C.c_int
     lib.pagk_frame_set_device.argtypes = [vp, i32, vp, i32, i32, C.c_int64, i32]
     lib.pagk_frame_download_level.restype = C.c_int

@@ -376,6 +376,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         // four features per wave: no NCC epilogue of its own (calc_ncc launches run the one-wave-per-feature variant)
         // ... and with the four rows of a wave independent + a work queue (pagk_rows_kernel.h)
         ctx->last_handover = false;
+        // the reference's defaults (no regularisation penalty, solver_variant 0) run kernels in which both are
+        // compile-time facts (LEAN); everything else runs the generic instantiations
+        const bool lean = !a.penalty && a.solver == 0;
         const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
         const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
@@ -477,9 +480,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 return hipGetLastError();
             };
             hipError_t e = hipErrorInvalidValue;
-            if (a.half == 5) e = launch(k_track_quad<2>);        // P = 121: 2 chunks of 64 pixels
-            else if (a.half == 7) e = launch(k_track_quad<4>);   // P = 225
-            else if (a.half == 10) e = launch(k_track_quad<7>);  // P = 441
+            if (a.half == 5) e = lean ? launch(k_track_quad<2, true>) : launch(k_track_quad<2>);        // P = 121: 2 chunks of 64 pixels
+            else if (a.half == 7) e = lean ? launch(k_track_quad<4, true>) : launch(k_track_quad<4>);   // P = 225
+            else if (a.half == 10) e = lean ? launch(k_track_quad<7, true>) : launch(k_track_quad<7>);  // P = 441
             HIPCHK(ctx, e);
             if (live) {
                 const size_t lds = track_block_lds_bytes(a.half);
@@ -515,9 +518,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 return hipGetLastError();
             };
             hipError_t e = hipErrorInvalidValue;
-            if (a.half == 5) e = launch(k_track_wave<2, 25>);        // P = 121
-            else if (a.half == 7) e = launch(k_track_wave<4, 1>);    // P = 225
-            else if (a.half == 10) e = launch(k_track_wave<7, 25>);  // P = 441
+            if (a.half == 5) e = lean ? launch(k_track_wave<2, 25, true>) : launch(k_track_wave<2, 25>);        // P = 121
+            else if (a.half == 7) e = lean ? launch(k_track_wave<4, 1, true>) : launch(k_track_wave<4, 1>);    // P = 225
+            else if (a.half == 10) e = lean ? launch(k_track_wave<7, 25, true>) : launch(k_track_wave<7, 25>);  // P = 441
             HIPCHK(ctx, e);
         } else if (ctx->kernel == 4 && mfma_ok) {
             // relaxed-order experiment (NOT parity-exact; never chosen automatically)
@@ -539,9 +542,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             };
             hipError_t e = hipErrorInvalidValue;
             (void)Pm;
-            if (a.half == 5) e = launch(k_track_block<1, 25, 2, true>);        // P = 121
-            else if (a.half == 7) e = launch(k_track_block<2, 1, 2, true>);    // P = 225
-            else if (a.half == 10) e = launch(k_track_block<4, 25, 2, true>);  // P = 441
+            if (a.half == 5) e = lean ? launch(k_track_block<1, 25, 2, true, false, true>) : launch(k_track_block<1, 25, 2, true>);        // P = 121
+            else if (a.half == 7) e = lean ? launch(k_track_block<2, 1, 2, true, false, true>) : launch(k_track_block<2, 1, 2, true>);    // P = 225
+            else if (a.half == 10) e = lean ? launch(k_track_block<4, 25, 2, true, false, true>) : launch(k_track_block<4, 25, 2, true>);  // P = 441
             HIPCHK(ctx, e);
         } else {
             const int P = (2 * a.half + 1) * (2 * a.half + 1);
@@ -574,17 +577,17 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 if (pyr_done) *pyr_done = true;
             } else
             switch (nr * 100 + tail) {
-                case 101: e = launch(k_track_block<1, 1>); break;    // h = 7
-                case 109: e = launch(k_track_block<1, 9>); break;    // h = 1, 6
-                case 117: e = launch(k_track_block<1, 17>); break;   // h = 3, 4
-                case 125: e = launch(k_track_block<1, 25>); break;   // h = 2, 5
-                case 201: e = launch(k_track_block<2, 1>); break;    // h = 8
-                case 209: e = launch(k_track_block<2, 9>); break;    // h = 9
-                case 225: e = launch(k_track_block<2, 25>); break;   // h = 10
-                case 317: e = launch(k_track_block<3, 17>); break;   // h = 11, 12
-                case 325: e = launch(k_track_block<3, 25>); break;   // h = 13
-                case 409: e = launch(k_track_block<4, 9>); break;    // h = 14
-                case 401: e = launch(k_track_block<4, 1>); break;    // h = 15
+                case 101: e = lean ? launch(k_track_block<1, 1, 4, false, false, true>) : launch(k_track_block<1, 1>); break;    // h = 7
+                case 109: e = lean ? launch(k_track_block<1, 9, 4, false, false, true>) : launch(k_track_block<1, 9>); break;    // h = 1, 6
+                case 117: e = lean ? launch(k_track_block<1, 17, 4, false, false, true>) : launch(k_track_block<1, 17>); break;   // h = 3, 4
+                case 125: e = lean ? launch(k_track_block<1, 25, 4, false, false, true>) : launch(k_track_block<1, 25>); break;   // h = 2, 5
+                case 201: e = lean ? launch(k_track_block<2, 1, 4, false, false, true>) : launch(k_track_block<2, 1>); break;    // h = 8
+                case 209: e = lean ? launch(k_track_block<2, 9, 4, false, false, true>) : launch(k_track_block<2, 9>); break;    // h = 9
+                case 225: e = lean ? launch(k_track_block<2, 25, 4, false, false, true>) : launch(k_track_block<2, 25>); break;   // h = 10
+                case 317: e = lean ? launch(k_track_block<3, 17, 4, false, false, true>) : launch(k_track_block<3, 17>); break;   // h = 11, 12
+                case 325: e = lean ? launch(k_track_block<3, 25, 4, false, false, true>) : launch(k_track_block<3, 25>); break;   // h = 13
+                case 409: e = lean ? launch(k_track_block<4, 9, 4, false, false, true>) : launch(k_track_block<4, 9>); break;    // h = 14
+                case 401: e = lean ? launch(k_track_block<4, 1, 4, false, false, true>) : launch(k_track_block<4, 1>); break;    // h = 15
                 default: break;
             }
             if (!(pyr_done && *pyr_done)) HIPCHK(ctx, e);

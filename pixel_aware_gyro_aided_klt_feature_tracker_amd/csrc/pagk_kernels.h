@@ -506,7 +506,11 @@ __device__ __forceinline__ float relaxed_row_f32(const float *arr, int P, int lr
 }
 
 // `i`: the feature; `resume`: nullptr, or the state a throughput kernel suspended the feature in (k_track_resume).
-template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
+// LEAN: the launch is known to run without the regularisation penalty and with solver_variant 0 (the reference's
+// defaults, BASELINE's configs): both become compile-time facts.  A lone wave pays ~6 cycles per instruction, and the
+// generic form spends ~55 of the solve's ~390 on them -- the selects of the five association switches, the Eigen <= 3.2
+// reciprocal path computed beside the division, and twenty register copies where the penalty's branch rejoins.
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false, bool LEAN = false>
 __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i, const SuspState *resume = nullptr)
 {
     static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
@@ -942,9 +946,11 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                     b[3] = acc[10];
                 }
                 float cost = sh_cost[0];
-                if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+                if constexpr (!LEAN) {
+                    if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+                }
                 // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
-                double unorm = llt4_solve_nsq_lanes(H, b, tid, upd, a.solver);  // update.squaredNorm()
+                double unorm = llt4_solve_nsq_lanes(H, b, tid, upd, LEAN ? 0u : a.solver);  // update.squaredNorm()
 #ifdef PAGK_COUNT_REDO
                 if (a.dbg) {
                     OperandRange rg;
@@ -1080,10 +1086,10 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
 // second argument = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs).  For the 4-wave kernel that is
 // four workgroups per CU, i.e. all 1000 features of BASELINE configs[1] resident at once on 256 CUs (checked against
 // the code object by __graft_entry__.build()).
-template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false>
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false, bool LEAN = false>
 __global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
 {
-    track_block_body<NR, TAIL, WAVES, MFMA, RELAXED>(a, (int)blockIdx.x);
+    track_block_body<NR, TAIL, WAVES, MFMA, RELAXED, LEAN>(a, (int)blockIdx.x);
 }
 
 // The latency kernel as the second pass of a large launch: finishes the features a throughput kernel suspended

@@ -117,7 +117,7 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
     b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
 }
 
-template <int NCH>
+template <int NCH, bool LEAN = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
     __shared__ __attribute__((aligned(256))) QuadLds S;
@@ -341,11 +341,13 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             double H[4][4], b[4], upd[4];
             quad_read_system(S, row, P, cd, H, b);
             float cost = carry;
-            if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+            if constexpr (!LEAN) {
+                if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+            }
             double unorm = 0.0;
             // (rows without an iterating feature hold stale sums: they sit the solve out, so that only live systems can
             // raise the exception flags that send the wave to the plain-division form)
-            if (act) unorm = llt4_solve_nsq(H, b, upd, a.solver);  // update.squaredNorm()
+            if (act) unorm = llt4_solve_nsq(H, b, upd, LEAN ? 0u : a.solver);  // update.squaredNorm()
             __syncthreads();  // the accumulators' LDS is the next iteration's first chunk
             // ---- update + termination (:322-344), per feature ------------------------------------------
             if (act) {

@@ -43,7 +43,7 @@ __host__ __device__ inline size_t track_wave_lds_bytes(int half)
     return region * 4 + 8 + 24 * 8 + 5 * 8 + 2 * 4 + 8;
 }
 
-template <int NR, int TAIL>
+template <int NR, int TAIL, bool LEAN = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -241,9 +241,11 @@ __global__ void __launch_bounds__(64, PAGK_WAVE_OCC) k_track_wave(TrackArgs a)
                     for (int c = 0; c <= r; c++) H[r][c] = acc[r * 4 + c];
                 for (int r = 0; r < 4; r++) b[r] = acc[16 + r];
                 float cost = sh_cost[0];
-                if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+                if constexpr (!LEAN) {
+                    if (a.penalty) add_penalty(a, dx, dy, H, b, cost);
+                }
                 // four lanes share the divides of each Cholesky column (pagk_device.h); all end with the result
-                double unorm = llt4_solve_nsq_lanes(H, b, lane, upd, a.solver);  // update.squaredNorm()
+                double unorm = llt4_solve_nsq_lanes(H, b, lane, upd, LEAN ? 0u : a.solver);  // update.squaredNorm()
                 if (lane == 0) {
                     sh_upd[0] = upd[0];
                     sh_upd[1] = upd[1];
