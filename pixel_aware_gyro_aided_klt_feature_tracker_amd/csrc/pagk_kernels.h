@@ -908,12 +908,21 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                     if (lane == 15) sh_cost[0] = c;
                 }
             } else if (wave < 2) {
-                double s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
+                // (two-round patches: the block count is a compile-time constant -> the fully unrolled routine)
+                double s;
+                if constexpr (HC != 0)
+                    s = chain_rows_f64_unrolled<(2 * HC + 1) * (2 * HC + 1) / 32, TAIL>(row_addr, row_s1);
+                else
+                    s = chain_rows_f64<TAIL>(row_addr, row_inc, nfull, row_s1);
                 // slots as the solve reads them: H00 H10 H11 b0 b1 H20 H21 H30 H31 b2 b3 H22
                 if (lr == 0) acc[cid == 7 ? 9 : cid] = s;              // lane 0: H00 H10 H11 b0 | b1 H20 H21 b2
                 if (lr == 1 && cid >= 5) acc[cid == 7 ? 10 : cid + 2] = s;  // lane 1 of rows X Y E: H30 H31 b3
             } else if (wave == 2) {
-                float c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
+                float c;
+                if constexpr (HC != 0)
+                    c = chain_rows_f32_unrolled<(2 * HC + 1) * (2 * HC + 1) / 32, TAIL>(row_addr);
+                else
+                    c = chain_rows_f32<TAIL>(row_addr, row_inc, nfull);
                 if (lane == 0) sh_cost[0] = c;
             } else if (iter == iter_first) {
                 // H22 = the ordered sum of P copies of c*c: the same value in every iteration of this level
