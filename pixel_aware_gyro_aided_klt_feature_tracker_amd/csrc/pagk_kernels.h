@@ -991,6 +991,8 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             __builtin_amdgcn_s_setprio(0);
             STAMP(3)
             // ---- 4. update + termination, identically in every lane (:322-344) -----------------
+            // (the compiler sinks these reads behind the exit tests that precede their first use: three LDS round trips;
+            // forcing one batch was measured and changes nothing, profiles/r03_ab12_update_reads.log)
             const double u0 = sh_upd[0], u1 = sh_upd[1], u2 = sh_upd[2], u3 = sh_upd[3], unorm = sh_upd[4];
             const float cost = sh_cost[1];
             if (u0 != u0) {  // :322
