@@ -248,12 +248,13 @@ int pagk_post_filter(int32_t n, int32_t half_patch, const uint8_t *status_pm,
  * (src/patch_match.cpp:319,343) on the caller's operands, so that a host can check on its own device -- and, with
  * Eigen at hand, against its own Eigen -- what pagk_params::solver_variant selects.
  * pagk_selftest_divide: per item i, q_plain[i] = num[i] / den[i] (the compiler's correctly rounded division),
- * q_prepared[i] = the same quotient through the prepared-denominator form the kernels use, root[i] = sqrt(num[i]).
+ * q_prepared[i] = the same quotient through the prepared-denominator form the kernels use, root[i] = sqrt(num[i]),
+ * root_lean[i] = the same root through the solve's ten-instruction form (plain where num[i] is outside its range).
  * pagk_selftest_solve: per 4x4 system (H row-major, lower triangle read; b) the update x and its norm from the
  * one-lane form (x_serial, norm_serial = sqrt of the squared norm) and from the four-lane form (x_lanes, nsq_lanes =
  * the squared norm the kernels compare with the threshold equivalent to `norm < 1e-2`).  Host pointers. */
 int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const double *den, double *q_plain,
-                         double *q_prepared, double *root);
+                         double *q_prepared, double *root, double *root_lean);
 int pagk_selftest_solve(pagk_ctx *ctx, int32_t n, const double *H, const double *b, uint32_t solver_variant,
                         double *x_serial, double *norm_serial, double *x_lanes, double *nsq_lanes);
 

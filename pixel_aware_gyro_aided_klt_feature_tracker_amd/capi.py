@@ -205,7 +205,7 @@ def declare(lib) -> None:
     lib.pagk_ncc_free.argtypes = [vp, _P(Image), _P(Image), i32, i32, vp, vp, vp, vp]
     if hasattr(lib, "pagk_selftest_divide"):   # (absent from older builds that tools/ab_lib.py loads for A/B runs)
         lib.pagk_selftest_divide.restype = C.c_int
-        lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         lib.pagk_selftest_solve.restype = C.c_int
         lib.pagk_selftest_solve.argtypes = [vp, i32, vp, vp, C.c_uint32, vp, vp, vp, vp]
     lib.pagk_match_features.restype = C.c_int
@@ -459,13 +459,14 @@ class Context:
         return out[:n]
 
     def selftest_divide(self, num: np.ndarray, den: np.ndarray):
-        """(num / den, the same through the prepared-denominator form, sqrt(num)) computed on the device."""
+        """(num / den, the same through the prepared-denominator form, sqrt(num), sqrt(num) through the solve's lean form)
+        computed on the device."""
         num, den = np.ascontiguousarray(num, np.float64), np.ascontiguousarray(den, np.float64)
         n = int(num.shape[0])
-        qp, qq, rt = (np.zeros(max(n, 1), np.float64) for _ in range(3))
-        self._check(self.lib.pagk_selftest_divide(self.h, n, _ptr(num), _ptr(den), _ptr(qp), _ptr(qq), _ptr(rt)),
+        qp, qq, rt, rl = (np.zeros(max(n, 1), np.float64) for _ in range(4))
+        self._check(self.lib.pagk_selftest_divide(self.h, n, _ptr(num), _ptr(den), _ptr(qp), _ptr(qq), _ptr(rt), _ptr(rl)),
                     "pagk_selftest_divide")
-        return qp[:n], qq[:n], rt[:n]
+        return qp[:n], qq[:n], rt[:n], rl[:n]
 
     def selftest_solve(self, H: np.ndarray, b: np.ndarray, solver_variant: int = 0):
         """H.llt().solve(b) and the update's norm for n 4x4 systems: (x, norm) of the one-lane form and

@@ -508,6 +508,39 @@ __device__ __forceinline__ double div_by(double n, const Den &D, OperandRange &r
         return n / D.d;
     }
 }
+// pivot -> diagonal entry: sqrt(x) for an accepted pivot, the untouched H(k,k) otherwise.  hipcc expands an f64 sqrt
+// into a range test + v_ldexp (scaling for x < 2^-767), v_rsq_f64, two coupled Newton steps on (g, h) ~ (sqrt x,
+// 1 / (2 sqrt x)), two residual corrections, the scaling back and a v_cmp_class fix-up for 0 / inf: 22 instructions, of
+// which the scalings and the fix-up are identities for a pivot inside the range the divisions require anyway.  FAST: the
+// ten instructions that remain, in the compiler's order, hence its bits (tests/test_solver_gpu.py); the pivot joins the
+// operand range (a rejected pivot does not: its root is never formed, and H is singular -- the 4th pivot fails in most solves).
+template <bool FAST>
+__device__ __forceinline__ double pivot_root(bool ok, double x, double hkk, OperandRange &rg)
+{
+    if constexpr (FAST) {
+        const double xs = ok ? x : 1.0;
+        rg.add(xs);
+        const double y = __builtin_amdgcn_rsq(xs);
+        double g = xs * y, h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, xs);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, xs);
+        g = __builtin_fma(d, h, g);
+        return ok ? g : hkk;
+    } else {
+        return ok ? sqrt(x) : hkk;
+    }
+}
+// the lean square root by itself, with the plain one where the operand is out of its range (diagnostics)
+__device__ __forceinline__ double sqrt_one(double x)
+{
+    OperandRange rg;
+    const double g = pivot_root<true>(true, x, x, rg);
+    return (rg.in_range() && x > 0.0) ? g : sqrt(x);
+}
 // the checked single division (diagnostics: pagk_selftest_divide)
 __device__ __forceinline__ double div_one(double n, double d)
 {
@@ -554,7 +587,7 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     auto scale = [&](double n, const Den &D, double rx) { return recip ? n * rx : div_by<FAST>(n, D, rg); };
     // column 0
     const bool ok0 = !(H00 <= 0.0);
-    const double d0 = ok0 ? sqrt(H00) : H00;
+    const double d0 = pivot_root<FAST>(ok0, H00, H00, rg);
     const Den D0 = den_prepare<FAST>(d0, rg);
     double rx = recip ? div_by<FAST>(1.0, D0, rg) : 0.0;
     const double q10 = scale(H10, D0, rx), q20 = scale(H20, D0, rx), q30 = scale(H30, D0, rx);
@@ -563,7 +596,7 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     // column 1
     const double x1 = H11 - L10 * L10;
     const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double d1 = ok1 ? sqrt(x1) : H11;
+    const double d1 = pivot_root<FAST>(ok1, x1, H11, rg);
     const Den D1 = den_prepare<FAST>(d1, rg);
     rx = recip ? div_by<FAST>(1.0, D1, rg) : 0.0;
     const double q21 = scale(H21 - L20 * L10, D1, rx), q31 = scale(H31 - L30 * L10, D1, rx);
@@ -574,7 +607,7 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     s += L21 * L21;
     const double x2 = H22 - s;
     const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double d2 = ok2 ? sqrt(x2) : H22;
+    const double d2 = pivot_root<FAST>(ok2, x2, H22, rg);
     const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
@@ -586,7 +619,7 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     const double a0 = L30 * L30, a1 = L31 * L31, a2 = L32 * L32;
     const double x3 = H33 - ((sv & SV_PIVOT_TREE) ? a0 + (a1 + a2) : (a0 + a1) + a2);
     const bool ok3 = ok2 && !(x3 <= 0.0);
-    const double d3 = ok3 ? sqrt(x3) : H33;
+    const double d3 = pivot_root<FAST>(ok3, x3, H33, rg);
     const Den D3 = den_prepare<FAST>(d3, rg);
     // L y = b, last row (the rows above are interleaved with their columns): c0 + (c1 + c2)
     const double c0 = L30 * r0, c1 = L31 * r1, c2 = L32 * r2;
@@ -644,7 +677,7 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     };
     // column 0: lane 0 -> r0 = b0 / d0, lane i -> L(i,0) = H(i,0) / d0
     const bool ok0 = !(H00 <= 0.0);
-    const double d0 = ok0 ? sqrt(H00) : H00;
+    const double d0 = pivot_root<FAST>(ok0, H00, H00, rg);
     const Den D0 = den_prepare<FAST>(d0, rg);
     const double n0 = l == 0 ? b[0] : (l == 1 ? H10 : (l == 2 ? H20 : H30));
     const double q0 = column(n0, D0, l == 0);
@@ -654,7 +687,7 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     // column 1: lane 1 -> r1, lanes 2, 3 -> L(i,1)
     const double x1 = H11 - L10 * L10;
     const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double d1 = ok1 ? sqrt(x1) : H11;
+    const double d1 = pivot_root<FAST>(ok1, x1, H11, rg);
     const Den D1 = den_prepare<FAST>(d1, rg);
     const double h1 = l == 2 ? H21 : H31;
     const double n1 = l == 1 ? b[1] - L10 * r0 : h1 - (l == 2 ? L20 : L30) * L10;
@@ -667,7 +700,7 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     s += L21 * L21;
     const double x2 = H22 - s;
     const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double d2 = ok2 ? sqrt(x2) : H22;
+    const double d2 = pivot_root<FAST>(ok2, x2, H22, rg);
     const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
@@ -680,7 +713,7 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     const double a0 = L30 * L30, a1 = L31 * L31, a2 = L32 * L32;
     const double x3 = H33 - ((sv & SV_PIVOT_TREE) ? a0 + (a1 + a2) : (a0 + a1) + a2);
     const bool ok3 = ok2 && !(x3 <= 0.0);
-    const double d3 = ok3 ? sqrt(x3) : H33;
+    const double d3 = pivot_root<FAST>(ok3, x3, H33, rg);
     const Den D3 = den_prepare<FAST>(d3, rg);
     const double c0 = L30 * r0, c1 = L31 * r1, c2 = L32 * r2;
     const double r3 = div_by<FAST, true>(b[3] - ((sv & SV_LOWER_SEQ) ? (c0 + c1) + c2 : c0 + (c1 + c2)), D3, rg);

@@ -1565,25 +1565,26 @@ struct Scratch {
 }  // namespace
 
 int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const double *den, double *q_plain,
-                         double *q_prepared, double *root)
+                         double *q_prepared, double *root, double *root_lean)
 {
     if (!ctx || n < 0) return PAGK_E_ARG;
     NOT_WHILE_CAPTURING(ctx, "pagk_selftest_divide");
     if (n == 0) return PAGK_OK;
-    if (!num || !den || !q_plain || !q_prepared || !root) return PAGK_E_ARG;
+    if (!num || !den || !q_plain || !q_prepared || !root || !root_lean) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Scratch s;
     const size_t nb = (size_t)n * sizeof(double);
-    HIPCHK(ctx, hipMalloc(&s.p, 5 * nb));
+    HIPCHK(ctx, hipMalloc(&s.p, 6 * nb));
     double *d = static_cast<double *>(s.p);
     HIPCHK(ctx, hipMemcpyAsync(d, num, nb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d + n, den, nb, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_selftest_divide, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d, d + n, d + 2 * (size_t)n,
-                       d + 3 * (size_t)n, d + 4 * (size_t)n);
+                       d + 3 * (size_t)n, d + 4 * (size_t)n, d + 5 * (size_t)n);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(q_plain, d + 2 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q_prepared, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(root, d + 4 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(root_lean, d + 5 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PAGK_OK;
 }

@@ -13,7 +13,7 @@
 namespace pagk {
 
 __global__ void __launch_bounds__(256) k_selftest_divide(int n, const double *num, const double *den, double *q_plain,
-                                                         double *q_prepared, double *root)
+                                                         double *q_prepared, double *root, double *root_lean)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(256) k_selftest_divide(int n, const double *nu
     q_plain[i] = a / d;
     q_prepared[i] = div_one(a, d);
     root[i] = sqrt(a);
+    root_lean[i] = sqrt_one(a);
 }
 
 // block = 64 threads = 16 systems: thread t solves system blockIdx * 16 + t / 4 with the four-lane form (lane t % 4);

@@ -51,13 +51,18 @@ def test_division_by_prepared_denominator(ctx):
     rng = np.random.default_rng(0xD1F1DE)
     n = 1 << 22
     num, den = _operands(rng, n), _operands(rng, n)
-    q_plain, q_prep, _ = ctx.selftest_divide(num, den)
+    q_plain, q_prep, root, root_lean = ctx.selftest_divide(np.where(num == 0, num, num), den)
     assert np.array_equal(_bits(q_plain), _bits(q_prep))
     with np.errstate(all="ignore"):
         host = num / den
     nan = np.isnan(host)
     assert np.array_equal(np.isnan(q_prep), nan)
     assert np.array_equal(_bits(q_prep[~nan]), _bits(host[~nan]))
+    # the solve's lean square root == the compiler's == the host's, on the same operands (negative -> NaN in all three)
+    rn = np.isnan(root)
+    assert np.array_equal(np.isnan(root_lean), rn) and np.array_equal(_bits(root_lean[~rn]), _bits(root[~rn]))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(_bits(root[~rn]), _bits(np.sqrt(num[~rn])))
 
 
 def test_norm_threshold_is_equivalent_to_the_square_root_test(ctx):
@@ -68,7 +73,8 @@ def test_norm_threshold_is_equivalent_to_the_square_root_test(ctx):
     near = (tb + np.arange(-(1 << 16), 1 << 16, dtype=np.int64).astype(np.uint64)).view(np.float64)
     rng = np.random.default_rng(7)
     s = np.concatenate([near, rng.random(1 << 16) * 3e-4, np.array([0.0, np.inf, np.nan, 1e-4, T])])
-    _, _, root = ctx.selftest_divide(s, np.ones_like(s))
+    _, _, root, root_lean = ctx.selftest_divide(s, np.ones_like(s))
+    assert np.array_equal(_bits(root[~np.isnan(s)]), _bits(root_lean[~np.isnan(s)]))
     with np.errstate(invalid="ignore"):
         assert np.array_equal(root < 1e-2, s < T)
         assert np.array_equal(_bits(root[~np.isnan(s)]), _bits(np.sqrt(s[~np.isnan(s)])))
