@@ -534,6 +534,28 @@ __device__ __forceinline__ double pivot_root(bool ok, double x, double hkk, Oper
         return ok ? sqrt(x) : hkk;
     }
 }
+// The first three pivots in the FAST form: taken as accepted.  They fail for flat or saturated patches only (the 4th
+// fails routinely: H is singular), so instead of carrying `ok ? ... : ...` selects through every column the pivot joins
+// the operand range as a POSITIVE value -- zero, negative or NaN sends the solve to the plain form, which implements
+// the reference's early return.
+template <bool FAST>
+__device__ __forceinline__ double pivot_root_early(bool ok, double x, double hkk, OperandRange &rg)
+{
+    if constexpr (FAST) {
+        rg.add_positive(x);
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, x);
+        return __builtin_fma(d, h, g);
+    } else {
+        return ok ? sqrt(x) : hkk;
+    }
+}
 // the lean square root by itself, with the plain one where the operand is out of its range (diagnostics)
 __device__ __forceinline__ double sqrt_one(double x)
 {
@@ -586,8 +608,8 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     // a column's scaling: A21 /= x (Eigen 3.3) or A21 *= 1/x (<= 3.2)
     auto scale = [&](double n, const Den &D, double rx) { return recip ? n * rx : div_by<FAST>(n, D, rg); };
     // column 0
-    const bool ok0 = !(H00 <= 0.0);
-    const double d0 = pivot_root<FAST>(ok0, H00, H00, rg);
+    const bool ok0 = FAST || (!(H00 <= 0.0));
+    const double d0 = pivot_root_early<FAST>(ok0, H00, H00, rg);
     const Den D0 = den_prepare<FAST>(d0, rg);
     double rx = recip ? div_by<FAST>(1.0, D0, rg) : 0.0;
     const double q10 = scale(H10, D0, rx), q20 = scale(H20, D0, rx), q30 = scale(H30, D0, rx);
@@ -595,8 +617,8 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     const double L10 = ok0 ? q10 : H10, L20 = ok0 ? q20 : H20, L30 = ok0 ? q30 : H30;
     // column 1
     const double x1 = H11 - L10 * L10;
-    const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double d1 = pivot_root<FAST>(ok1, x1, H11, rg);
+    const bool ok1 = FAST || (ok0 && !(x1 <= 0.0));
+    const double d1 = pivot_root_early<FAST>(ok1, x1, H11, rg);
     const Den D1 = den_prepare<FAST>(d1, rg);
     rx = recip ? div_by<FAST>(1.0, D1, rg) : 0.0;
     const double q21 = scale(H21 - L20 * L10, D1, rx), q31 = scale(H31 - L30 * L10, D1, rx);
@@ -606,8 +628,8 @@ __device__ __forceinline__ double llt4_solve_nsq_form(const double (&M)[4][4], c
     double s = L20 * L20;
     s += L21 * L21;
     const double x2 = H22 - s;
-    const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double d2 = pivot_root<FAST>(ok2, x2, H22, rg);
+    const bool ok2 = FAST || (ok1 && !(x2 <= 0.0));
+    const double d2 = pivot_root_early<FAST>(ok2, x2, H22, rg);
     const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
@@ -676,8 +698,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
         return fwd ? q : n * rx;
     };
     // column 0: lane 0 -> r0 = b0 / d0, lane i -> L(i,0) = H(i,0) / d0
-    const bool ok0 = !(H00 <= 0.0);
-    const double d0 = pivot_root<FAST>(ok0, H00, H00, rg);
+    const bool ok0 = FAST || (!(H00 <= 0.0));
+    const double d0 = pivot_root_early<FAST>(ok0, H00, H00, rg);
     const Den D0 = den_prepare<FAST>(d0, rg);
     const double n0 = l == 0 ? b[0] : (l == 1 ? H10 : (l == 2 ? H20 : H30));
     const double q0 = column(n0, D0, l == 0);
@@ -686,8 +708,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     const double L10 = lane_bcast(own0, 1), L20 = lane_bcast(own0, 2), L30 = lane_bcast(own0, 3);
     // column 1: lane 1 -> r1, lanes 2, 3 -> L(i,1)
     const double x1 = H11 - L10 * L10;
-    const bool ok1 = ok0 && !(x1 <= 0.0);
-    const double d1 = pivot_root<FAST>(ok1, x1, H11, rg);
+    const bool ok1 = FAST || (ok0 && !(x1 <= 0.0));
+    const double d1 = pivot_root_early<FAST>(ok1, x1, H11, rg);
     const Den D1 = den_prepare<FAST>(d1, rg);
     const double h1 = l == 2 ? H21 : H31;
     const double n1 = l == 1 ? b[1] - L10 * r0 : h1 - (l == 2 ? L20 : L30) * L10;
@@ -699,8 +721,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     double s = L20 * L20;
     s += L21 * L21;
     const double x2 = H22 - s;
-    const bool ok2 = ok1 && !(x2 <= 0.0);
-    const double d2 = pivot_root<FAST>(ok2, x2, H22, rg);
+    const bool ok2 = FAST || (ok1 && !(x2 <= 0.0));
+    const double d2 = pivot_root_early<FAST>(ok2, x2, H22, rg);
     const Den D2 = den_prepare<FAST>(d2, rg);
     s = L30 * L20;
     s += L31 * L21;
