@@ -762,18 +762,19 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             // (`interior ? issue<false> : issue<true>` per round) the two forms' loads share destination registers on
             // a control-flow path that cannot happen, and the compiler waits for every load in flight before each
             // round's gathers -- the rounds ran one after the other (profiles/r02_ab_runs.md).
-            constexpr int G = NR < 2 ? NR : 2;
             // Measured (same session, tools/ab_lib.py): 4-wave kernel -2.9 % at 250 features, -2.7 % at 1000, -2.2 % on
             // configs[2]; the 2-wave MFMA kernel (four rounds) +1.5 % (13 more spilled registers), so it keeps the choice
             // per round (mode 2).
-            auto sampling = [&](auto mode_tag) {
+            auto sampling = [&](auto mode_tag, auto rounds_tag) {
+            constexpr int NRX = decltype(rounds_tag)::value;  // rounds this wave samples (its later rounds lie past the patch)
+            constexpr int G = NRX < 2 ? NRX : 2;
             constexpr int MODE = decltype(mode_tag)::value;  // 0: clamp-free, 1: clamped, 2: chosen per round
 #pragma unroll
-            for (int r0 = 0; r0 < NR; r0 += G) {
+            for (int r0 = 0; r0 < NRX; r0 += G) {
                 FiveTaps taps[G];
 #pragma unroll
                 for (int u = 0; u < G; u++) {
-                    const int r = r0 + u < NR ? r0 + u : NR - 1;
+                    const int r = r0 + u < NRX ? r0 + u : NRX - 1;
                     float X = bx + wx[r], Y = by + wy[r];
                     if constexpr (MODE == 2)
                         taps[u] = interior ? sample5_issue<false>(L2, X, Y) : sample5_issue<true>(L2, X, Y);
@@ -795,7 +796,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
 #pragma unroll
                 for (int u = 0; u < G; u++) {
                     const int r = r0 + u;
-                    if (r >= NR) continue;
+                    if (r >= NRX) continue;
                     const Five s = sample5_finish(taps[u]);
                     const int p = tid + kBlock * r;
                     if (p < P) {
@@ -864,12 +865,28 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             if (staged) {
             } else
 #endif
-            if constexpr (MFMA)
-                sampling(std::integral_constant<int, 2>{});
-            else if (interior)
-                sampling(std::integral_constant<int, 0>{});
-            else
-                sampling(std::integral_constant<int, 1>{});
+            using AllRounds = std::integral_constant<int, NR>;
+            if constexpr (MFMA) {
+                sampling(std::integral_constant<int, 2>{}, AllRounds{});
+            } else if constexpr (HC != 0) {
+                // two-round patches: a wave whose 64 round-1 pixels all lie past the patch (wave 3 at h = 10) skips that
+                // round instead of sampling shadow pixels nobody stores (wave-uniform)
+                const bool one_round = wave * 64 + kBlock >= P;
+                if (one_round) {
+                    if (interior)
+                        sampling(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    else
+                        sampling(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                } else if (interior) {
+                    sampling(std::integral_constant<int, 0>{}, AllRounds{});
+                } else {
+                    sampling(std::integral_constant<int, 1>{}, AllRounds{});
+                }
+            } else if (interior) {
+                sampling(std::integral_constant<int, 0>{}, AllRounds{});
+            } else {
+                sampling(std::integral_constant<int, 1>{}, AllRounds{});
+            }
 #ifdef PAGK_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             STAMP(10)  // interpolation, products, LDS stores done in this wave
