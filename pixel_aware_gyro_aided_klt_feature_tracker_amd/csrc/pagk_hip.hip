@@ -170,9 +170,6 @@ int make_pyr_args(const FrameSlot &s, const uint8_t *src0, int64_t pitch0, int w
     pa.pitch = pitch0;
     pa.wrap0 = wrap0;
     pa.n_levels = s.L;
-    // level 0 four pixels per thread when the rows are dword-addressable (the 16-byte quad store needs cols % 4 == 0;
-    // the quad buffer itself is 256-byte aligned)
-    pa.x4 = (lw[0] % 4 == 0) && (pitch0 % 4 == 0) && (reinterpret_cast<uintptr_t>(src0) % 4 == 0) && !getenv("PAGK_PYR_SCALAR");
     int nb = 0;
     for (int l = 0; l < 4; l++) {
         pa.first_block[l] = nb;
@@ -181,8 +178,7 @@ int make_pyr_args(const FrameSlot &s, const uint8_t *src0, int64_t pitch0, int w
             pa.rows[l] = lh[l];
             pa.u8[l] = s.u8[l];
             pa.quad[l] = s.quad[l];
-            const int threads = (l == 0 && pa.x4) ? (lw[0] / 4) * lh[0] : lw[l] * lh[l];
-            nb += (threads + 255) / 256;
+            nb += (lw[l] * lh[l] + 255) / 256;
         }
     }
     pa.first_block[4] = nb;

@@ -101,7 +101,6 @@ struct PyrArgs {
     const uint8_t *src;  // level 0
     int64_t pitch;
     int wrap0;
-    int x4;              // level 0 in groups of four pixels per thread (cols, pitch and src multiples of 4)
     int n_levels;
     int cols[4], rows[4];
     int first_block[5];  // blocks [first_block[l], first_block[l+1]) belong to level l
@@ -149,46 +148,11 @@ __device__ __forceinline__ void pyr_emit(const PyrArgs &a, int idx)
     if constexpr (L > 0) a.u8[L][idx] = (uint8_t)d0;
 }
 
-// Level 0, four pixels per thread: the two image rows as one aligned dword load each (bytes c .. c+3), the fifth
-// byte of each row through the scalar path (it is the next row's first pixel at the end of a continuous row, :399-403),
-// the four quads as one 16-byte store.  Level 0 is three quarters of the pyramid's threads; this form has a quarter of
-// them and a quarter of the memory instructions.
-__device__ __forceinline__ void pyr_emit0_x4(const PyrArgs &a, int idx4)
-{
-    const int cols = a.cols[0], rows = a.rows[0], groups = cols >> 2;
-    if (idx4 >= groups * rows) return;
-    const int r = idx4 / groups, c = (idx4 - r * groups) << 2;
-    auto px = [&](int rr, int cc) -> uint32_t {
-        if (cc >= cols) {
-            if (!a.wrap0) return 0u;
-            cc -= cols;
-            rr += 1;
-        }
-        return rr < rows ? (uint32_t)a.src[(int64_t)rr * a.pitch + cc] : 0u;
-    };
-    const uint32_t top = *reinterpret_cast<const uint32_t *>(a.src + (int64_t)r * a.pitch + c);
-    const uint32_t bot = r + 1 < rows ? *reinterpret_cast<const uint32_t *>(a.src + (int64_t)(r + 1) * a.pitch + c) : 0u;
-    const uint32_t t4 = px(r, c + 4), b4 = px(r + 1, c + 4);
-    uint4 q;
-    auto quad = [&](int k, uint32_t tn, uint32_t bn) {
-        const uint32_t t0 = (top >> (8 * k)) & 0xffu, b0 = (bot >> (8 * k)) & 0xffu;
-        return t0 | (tn << 8) | (b0 << 16) | (bn << 24);
-    };
-    q.x = quad(0, (top >> 8) & 0xffu, (bot >> 8) & 0xffu);
-    q.y = quad(1, (top >> 16) & 0xffu, (bot >> 16) & 0xffu);
-    q.z = quad(2, top >> 24, bot >> 24);
-    q.w = quad(3, t4, b4);
-    *reinterpret_cast<uint4 *>(a.quad[0] + (int64_t)r * cols + c) = q;
-}
-
 // one 256-thread block of the fused pyramid (b = block index within the pyramid's own range)
 __device__ __forceinline__ void pyr_block(const PyrArgs &a, int b, int tid)
 {
     if (b < a.first_block[1]) {
-        if (a.x4)
-            pyr_emit0_x4(a, (b - a.first_block[0]) * 256 + tid);
-        else
-            pyr_emit<0>(a, (b - a.first_block[0]) * 256 + tid);
+        pyr_emit<0>(a, (b - a.first_block[0]) * 256 + tid);
     } else if (b < a.first_block[2]) {
         pyr_emit<1>(a, (b - a.first_block[1]) * 256 + tid);
     } else if (b < a.first_block[3]) {
