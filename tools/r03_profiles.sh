@@ -15,4 +15,4 @@ timeout -k 10 300 bash tools/profile.sh r03_bench > gpurun_out/r03p/profile_benc
 timeout -k 10 500 python3 bench.py > gpurun_out/bench_r03_bench.json 2> gpurun_out/r03p/bench.err || echo "bench failed" >> gpurun_out/r03p/failed.txt
 tail -c 400 gpurun_out/r03p/bench.err
 head -c 600 gpurun_out/bench_r03_bench.json
-cat gpurun_out/r03p/failed.txt 2>/dev/null
+if [ -f gpurun_out/r03p/failed.txt ]; then cat gpurun_out/r03p/failed.txt; fi
