@@ -77,12 +77,13 @@ struct pagk_ctx {
     bool last_handover = false;  // the last tracking launch used the hand-over (pagk_last_handover)
     int concurrency = 1;    // pagk_set_concurrency: contexts like this one running at the same time on the device
     int last_variant = -1;  // variant the last tracking launch used (pagk_last_variant)
-    // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r01_sweep_n.log):
-    // the 4-wave DPP kernel is fastest while every workgroup is resident (its latency is lowest), the
-    // 2-wave MFMA variant from ~2500 features, one wave per feature from ~10000.
-    int mfma_min_features = 2500;   // PAGK_MFMA_MIN
-    int wave_min_features = 10000;  // PAGK_WAVE_MIN
-    int quad_min_features = 8000;   // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h); profiles/r02_ab_runs.md
+    // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r03_sweep_n.log): after round
+    // 3's instruction diet the 4-wave DPP kernel is the fastest up to ~5000 features (it used to lose to the 2-wave MFMA
+    // variant from 2500; that variant no longer wins at any size and is selected explicitly only), one wave per feature
+    // wins between ~5000 and ~7000, four features per wave from there.
+    int mfma_min_features = 0x7fffffff;  // PAGK_MFMA_MIN
+    int wave_min_features = 5000;        // PAGK_WAVE_MIN
+    int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };

@@ -454,14 +454,14 @@ def test_single_homography_prediction_on_device(ctx):
 
 # ---- every BASELINE config at its own size ---------------------------------
 def test_config4_stream_shape_at_full_size(ctx):
-    """BASELINE configs[4]: one 1280x720 stream x 4000 keypoints.  The launch auto-selects the 2-wave MFMA variant
-    (>= 2500 features); checked against the oracle on a seeded subset of the features and, over all 4000, through
+    """BASELINE configs[4]: one 1280x720 stream x 4000 keypoints.  The launch auto-selects the 4-wave DPP kernel (the
+    fastest up to ~5000 features since round 3); checked against the oracle on a seeded subset of the features and, over all 4000, through
     size-independent properties: determinism, and invariance under a permutation of the feature order."""
     w = synth.config(4)
     assert w.img_ref.shape == (720, 1280) and w.n == 4000
     p = params_for(w)
     a = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
-    assert ctx.last_variant() == 2
+    assert ctx.last_variant() == 0
     b = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
     for k in ("pt_un", "pt_dist", "status", "pix_err", "dist_pred", "iters"):
         assert np.array_equal(a[k], b[k], equal_nan=True), f"non-deterministic {k}"
@@ -478,16 +478,16 @@ def test_config4_stream_shape_at_full_size(ctx):
     assert int(a["status"][:w.n].sum()) > 0.8 * w.n_active
 
 
-@pytest.mark.parametrize("hint,variant", [(1, 2), (8, 5)])
+@pytest.mark.parametrize("hint,variant", [(1, 0), (8, 5)])
 def test_config4_eight_concurrent_streams_on_one_gpu(ctx, hint, variant):
     """BASELINE configs[4] in its 8-stream form on ONE GPU: eight resident trackers of the 1280x720 x 4000 shape, each
     with its own streams and hipGraph, stepped interleaved (two frames each); every stream must reproduce the
-    single-stream result bit for bit -- without the concurrency hint (each launch picks the 2-wave MFMA variant, as if
+    single-stream result bit for bit -- without the concurrency hint (each launch picks the 4-wave kernel, as if
     it had the device to itself) and with pagk_set_concurrency(8) (8 x 4000 features: four features per wave)."""
     w = synth.config(4)
     p = params_for(w)
     single = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
-    assert ctx.last_variant() == 2
+    assert ctx.last_variant() == 0
     cams = []
     for _ in range(8):
         rt = runtime.ResidentTracker(p, device=0, concurrency=hint)
