@@ -491,9 +491,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     hipLaunchKernelGGL(kern, dim3(ctx->finisher_wgs), dim3(kBlock), lds, ctx->aux_stream, a);
                     return hipGetLastError();
                 };
-                if (a.half == 5) e = finisher(k_track_resume_live<1, 25>);
-                else if (a.half == 7) e = finisher(k_track_resume_live<1, 1>);
-                else e = finisher(k_track_resume_live<2, 25>);
+                if (a.half == 5) e = lean ? finisher(k_track_resume_live<1, 25, true>) : finisher(k_track_resume_live<1, 25>);
+                else if (a.half == 7) e = lean ? finisher(k_track_resume_live<1, 1, true>) : finisher(k_track_resume_live<1, 1>);
+                else e = lean ? finisher(k_track_resume_live<2, 25, true>) : finisher(k_track_resume_live<2, 25>);
                 HIPCHK(ctx, e);
                 HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -506,9 +506,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
                     return hipGetLastError();
                 };
-                if (a.half == 5) e = resume(k_track_resume<1, 25>);
-                else if (a.half == 7) e = resume(k_track_resume<1, 1>);
-                else e = resume(k_track_resume<2, 25>);
+                if (a.half == 5) e = lean ? resume(k_track_resume<1, 25, true>) : resume(k_track_resume<1, 25>);
+                else if (a.half == 7) e = lean ? resume(k_track_resume<1, 1, true>) : resume(k_track_resume<1, 1>);
+                else e = lean ? resume(k_track_resume<2, 25, true>) : resume(k_track_resume<2, 25>);
                 HIPCHK(ctx, e);
             }
         } else if (use_wave) {
@@ -571,9 +571,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     hipLaunchKernelGGL(kern, dim3(n + pyr_blocks), dim3(kBlock), lds, ctx->stream, a, *pyr);
                     return hipGetLastError();
                 };
-                if (a.half == 5) e = launch_pyr(k_track_block_pyr<1, 25>);
-                else if (a.half == 7) e = launch_pyr(k_track_block_pyr<1, 1>);
-                else e = launch_pyr(k_track_block_pyr<2, 25>);
+                if (a.half == 5) e = lean ? launch_pyr(k_track_block_pyr<1, 25, true>) : launch_pyr(k_track_block_pyr<1, 25>);
+                else if (a.half == 7) e = lean ? launch_pyr(k_track_block_pyr<1, 1, true>) : launch_pyr(k_track_block_pyr<1, 1>);
+                else e = lean ? launch_pyr(k_track_block_pyr<2, 25, true>) : launch_pyr(k_track_block_pyr<2, 25>);
                 HIPCHK(ctx, e);
                 if (pyr_done) *pyr_done = true;
             } else

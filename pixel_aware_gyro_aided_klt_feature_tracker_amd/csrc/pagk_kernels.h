@@ -1138,7 +1138,7 @@ __device__ __forceinline__ SuspState load_susp_state(const TrackArgs &a, int i)
 // list entry k to be published, finishes that feature with the 4-wave body and draws again.  It ends when the
 // throughput launch has ended (susp_count[2] == susp_waves) and its entry was not published -- or after susp_polls
 // looks, whatever happened: a bounded wait, k_track_resume sweeps up behind it.
-template <int NR, int TAIL>
+template <int NR, int TAIL, bool LEAN = false>
 __global__ void __launch_bounds__(256, 4) k_track_resume_live(TrackArgs a)
 {
     __shared__ int s_entry;
@@ -1167,7 +1167,7 @@ __global__ void __launch_bounds__(256, 4) k_track_resume_live(TrackArgs a)
         if (slot < 0) return;  // (uniform)
         const int i = ld_agent(a.susp_list + slot) - 1;
         const SuspState st = load_susp_state(a, i);
-        track_block_body<NR, TAIL, 4, false, false>(a, i, &st);
+        track_block_body<NR, TAIL, 4, false, false, LEAN>(a, i, &st);
         __syncthreads();  // LDS and s_entry are reused
         if (tid == 0) st_agent(a.susp_list + slot, -(i + 1));
     }
@@ -1175,7 +1175,7 @@ __global__ void __launch_bounds__(256, 4) k_track_resume_live(TrackArgs a)
 
 // The sweep after both: every published entry that is still waiting (all of them when the live finisher is not used).
 // A fixed grid walks the list; the count is read on the device, so the launch is the same whatever it is.
-template <int NR, int TAIL>
+template <int NR, int TAIL, bool LEAN = false>
 __global__ void __launch_bounds__(256, 4) k_track_resume(TrackArgs a)
 {
     const int count = *a.susp_count;
@@ -1184,7 +1184,7 @@ __global__ void __launch_bounds__(256, 4) k_track_resume(TrackArgs a)
         if (entry <= 0) continue;  // finished by the live finisher
         const int i = entry - 1;
         const SuspState st = load_susp_state(a, i);
-        track_block_body<NR, TAIL, 4, false, false>(a, i, &st);
+        track_block_body<NR, TAIL, 4, false, false, LEAN>(a, i, &st);
         __syncthreads();  // LDS is reused by the next feature
     }
 }
@@ -1193,14 +1193,14 @@ __global__ void __launch_bounds__(256, 4) k_track_resume(TrackArgs a)
 // [0, n) are features, blocks [n, n + pyramid blocks) run k_pyramid_fused's body on another frame slot.  For
 // pipelines that already hold frame k+1 while pair (k-1, k) is tracked (replays, or a camera loop that accepts
 // one frame of latency): the pyramid then costs no launch of its own and runs in the tracking launch's shadow.
-template <int NR, int TAIL>
+template <int NR, int TAIL, bool LEAN = false>
 __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs pa)
 {
     if ((int)blockIdx.x >= a.n) {
         pyr_block(pa, (int)blockIdx.x - a.n, (int)threadIdx.x);
         return;
     }
-    track_block_body<NR, TAIL, 4, false, false>(a, (int)blockIdx.x);
+    track_block_body<NR, TAIL, 4, false, false, LEAN>(a, (int)blockIdx.x);
 }
 
 }  // namespace pagk
