@@ -279,8 +279,17 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 // waited for together with taps in flight (a register holding a pending load, paired by the allocator
                 // with a live weight in a packed operand, costs a wait for everything issued before it)
                 float s1q[4];
+#ifdef PAGK_EXPERIMENT_RECOMPUTE_I1
+                // EXPERIMENT (never the product): the img1 sample of every pixel re-derived in every iteration (one more
+                // tap and interpolation per sampled pixel) instead of the per-wave global workspace written once per level
+                // -- VERDICT r2 item 2's question "does the workspace round trip cost time against recomputation":
+                // profiles/r03_quad_i1_workspace_vs_recompute.log.
+#pragma unroll
+                for (int f = 0; f < 4; f++) s1q[f] = sample<true>(L1, rl(ptx, 16 * f) + x, rl(pty, 16 * f) + y);
+#else
 #pragma unroll
                 for (int f = 0; f < 4; f++) s1q[f] = ws[(f * NCH + c) * 64];
+#endif
                 auto consume = [&](int f, const FiveTaps &tp) {
                     const int src = 16 * f;
                     const float s1v = f == 0 ? s1q[0] : f == 1 ? s1q[1] : f == 2 ? s1q[2] : s1q[3];
