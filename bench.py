@@ -78,7 +78,7 @@ def measured_traffic(workload_name: str, n: int, kernel: str):
 
 
 KERNEL_OF_VARIANT = {0: "k_track_block", 1: "k_track_thread", 2: "k_track_block", 3: "k_track_wave", 4: "k_track_block",
-                     5: "k_track_quad", 6: "k_track_rows"}
+                     5: "k_track_quad", 6: "k_track_rows", 7: "k_track_quad"}
 
 
 def metric_label(w) -> str:

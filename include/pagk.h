@@ -193,7 +193,13 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  *     context alone on the device, not inside a graph capture) hands the features that have run 20 iterations to the
  *     4-wave latency kernel, which runs beside it on the context's auxiliary stream; results are the same bits.
  * 6 = 5 with the four rows of a wave independent (each row runs its own feature at its own level and takes the next
- *     feature from a work queue when it is done; a resident grid): bit-identical like 0-3. */
+ *     feature from a work queue when it is done; a resident grid): bit-identical like 0-3.
+ * 7 = 5 with one pyramid LEVEL per wavefront: pyramids x ceil(n / 4) wavefronts, each a third (a quarter) of the
+ *     lifetime of a whole-feature wavefront, a quad handed from its level to the next through device memory (the
+ *     waiting wavefront always waits for one that started earlier; the wait is bounded all the same and a launch in
+ *     which one ran out reports PAGK_E_HIP at the next synchronisation).  For launches of about one to two rounds of
+ *     resident wavefronts, which otherwise end with most of the device idle.  Bit-identical like 0-3.  With one
+ *     pyramid level, or calc_ncc, it is 5. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
 /* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
  * -1 before the first launch. */

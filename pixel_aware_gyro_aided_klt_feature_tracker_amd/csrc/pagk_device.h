@@ -70,8 +70,13 @@ struct TrackArgs {
     int susp_lone;     // suspend a feature only when no other row of its wave is iterating
     int susp_waves;    // waves of the throughput launch (what susp_count[2] reaches)
     int susp_polls;    // how often a finisher workgroup looks for its entry before it gives up (bounded: never a hang)
-    // k_track_rows: the next feature index to hand out (zeroed before every launch)
+    // k_track_rows: the next feature index to hand out (zeroed before every launch); k_track_quad<.., LEVELS>: the ticket
     int *queue;
+    // k_track_quad<.., LEVELS>: lv_done[quad] = level steps finished (zeroed before every launch), lv_state[4 feature] =
+    // (p2x, p2y, iterations so far, -) handed from one level's wave to the next, lv_error: a wait ran out
+    int *lv_done;
+    float *lv_state;
+    int *lv_error;
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)

@@ -55,6 +55,10 @@ struct pagk_ctx {
     int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
     size_t susp_bytes = 0;
+    void *lv = nullptr;       // one-level-per-wave launches: 8 ticket counters (1024 B) | int done[quads] | float state[4 n]
+    size_t lv_bytes = 0;
+    int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
+    int *lv_error_dev = nullptr;  // ... as the device addresses it
     hipStream_t aux_stream = nullptr;  // the live finisher's stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int susp_lone = 1;        // PAGK_SUSPEND_LONE=0: hand every feature over at the budget, not only the last of a wave
@@ -284,6 +288,18 @@ void fill_level(DevLevel &d, const FrameSlot &s, int l)
 // (pagk_set_concurrency) has other launches to fill its tail.  profiles/r02_ab_runs.md.
 // Resident waves of k_track_quad<NCH> on this device: the kernel's own occupancy (registers, its 10000 B of LDS) times
 // the CU count, asked once per context and patch size.
+// A wave of a one-level-per-wave launch that gave up waiting for the level above (never expected: the wait is on a wave
+// that started earlier) leaves results that must not be used.
+int lv_check(pagk_ctx *ctx)
+{
+    if (ctx->lv_error && *static_cast<volatile int *>(ctx->lv_error) != 0) {
+        *static_cast<volatile int *>(ctx->lv_error) = 0;
+        snprintf(ctx->err, sizeof(ctx->err), "a wave of the level-by-level tracking launch gave up waiting for the level above");
+        return PAGK_E_HIP;
+    }
+    return PAGK_OK;
+}
+
 int quad_capacity(pagk_ctx *ctx, int half)
 {
     const int slot = half == 5 ? 0 : (half == 7 ? 1 : 2);
@@ -382,10 +398,13 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool lean = !a.penalty && a.solver == 0;
         const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
-        const bool use_quad = !use_rows && mfma_ok && !a.calc_ncc && (ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
-        const bool use_wave = !use_quad && !use_rows && mfma_ok && (ctx->kernel == 3 || ctx->kernel == 5 || ctx->kernel == 6 || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
+        // four features per wave, one level per wave (needs more than one level to differ from the quad kernel)
+        const bool use_levels = mfma_ok && !a.calc_ncc && p->pyramids >= 2 && ctx->lv_error && ctx->kernel == 7;
+        const bool quad_like = ctx->kernel == 5 || ctx->kernel == 6 || ctx->kernel == 7;
+        const bool use_quad = !use_rows && !use_levels && mfma_ok && !a.calc_ncc && (quad_like || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
+        const bool use_wave = !use_quad && !use_rows && !use_levels && mfma_ok && (ctx->kernel == 3 || quad_like || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
         const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n_sel >= ctx->mfma_min_features));
-        ctx->last_variant = ctx->kernel == 1 ? 1 : use_rows ? 6 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
+        ctx->last_variant = ctx->kernel == 1 ? 1 : use_levels ? 7 : use_rows ? 6 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
         } else if (use_rows) {
@@ -426,6 +445,48 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             if (a.half == 5) e = launch(k_track_rows<2>);
             else if (a.half == 7) e = launch(k_track_rows<4>);
             else if (a.half == 10) e = launch(k_track_rows<7>);
+            HIPCHK(ctx, e);
+        } else if (use_levels) {
+            // pagk_quad_kernel.h, LEVELS: pyramids x ceil(n / 4) waves, each one level of four features
+            const int nch = (Pm + 63) / 64, nq = (n + 3) / 4, waves = nq * p->pyramids;
+            const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
+            const size_t need_lv = 1024 + align_up((size_t)nq * 4, 256) + (size_t)n * 16;
+            if (need > ctx->quad_ws_bytes || need_lv > ctx->lv_bytes) {
+                if (ctx->capturing) {
+                    snprintf(ctx->err, sizeof(ctx->err), "the level kernel's workspace would have to be (re)allocated during graph capture");
+                    return PAGK_E_ARG;
+                }
+                if (need > ctx->quad_ws_bytes) {
+                    if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
+                    ctx->quad_ws = nullptr;
+                    ctx->quad_ws_bytes = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->quad_ws, need));
+                    ctx->quad_ws_bytes = need;
+                }
+                if (need_lv > ctx->lv_bytes) {
+                    if (ctx->lv) HIPCHK(ctx, hipFree(ctx->lv));
+                    ctx->lv = nullptr;
+                    ctx->lv_bytes = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->lv, need_lv));
+                    ctx->lv_bytes = need_lv;
+                }
+            }
+            uint8_t *lb = static_cast<uint8_t *>(ctx->lv);
+            a.ws = static_cast<float *>(ctx->quad_ws);
+            a.queue = reinterpret_cast<int *>(lb);
+            a.lv_done = reinterpret_cast<int *>(lb + 1024);
+            a.lv_state = reinterpret_cast<float *>(lb + 1024 + align_up((size_t)nq * 4, 256));
+            a.lv_error = ctx->lv_error_dev;
+            a.susp_polls = ctx->finisher_polls;
+            HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + (size_t)nq * 4, ctx->stream));  // tickets and flags
+            auto launch = [&](auto kern) -> hipError_t {
+                hipLaunchKernelGGL(kern, dim3(waves), dim3(64), 0, ctx->stream, a);
+                return hipGetLastError();
+            };
+            hipError_t e = hipErrorInvalidValue;
+            if (a.half == 5) e = lean ? launch(k_track_quad<2, true, true>) : launch(k_track_quad<2, false, true>);
+            else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true>) : launch(k_track_quad<4, false, true>);
+            else if (a.half == 10) e = lean ? launch(k_track_quad<7, true, true>) : launch(k_track_quad<7, false, true>);
             HIPCHK(ctx, e);
         } else if (use_quad) {
             const int nch = (Pm + 63) / 64;
@@ -699,6 +760,7 @@ int track_host_common(pagk_ctx *ctx, const pagk_params *p, int n, const float *p
         HIPCHK(ctx, hipMemcpyAsync(hb + fp.in_bytes, db + fp.in_bytes, fp.total - fp.in_bytes, hipMemcpyDeviceToHost,
                                    ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int lr = lv_check(ctx)) return lr;
     if (n > 0) {
         size_t nn = (size_t)n;
         memcpy(out->pt_un, hb + fp.offs[4], nn * 8);
@@ -787,6 +849,19 @@ int pagk_create(pagk_ctx **out, int device)
         pagk_destroy(ctx);
         return PAGK_E_NOMEM;
     }
+    {   // the error word of the one-level-per-wave launches lives in mapped host memory: read at a sync without a copy
+        void *hp = nullptr;
+        void *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+            memset(hp, 0, 64);
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+                ctx->lv_error = static_cast<int *>(hp);
+                ctx->lv_error_dev = static_cast<int *>(dp);
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+    }
     ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
@@ -836,6 +911,8 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->quad_ws) (void)hipFree(ctx->quad_ws);
     if (ctx->susp) (void)hipFree(ctx->susp);
     if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->lv) (void)hipFree(ctx->lv);
+    if (ctx->lv_error) (void)hipHostFree(ctx->lv_error);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
         if (ctx->ev_pyr[k]) (void)hipEventDestroy(ctx->ev_pyr[k]);
@@ -853,7 +930,7 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
 
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
-    if (!ctx || which < 0 || which > 6) return PAGK_E_ARG;
+    if (!ctx || which < 0 || which > 7) return PAGK_E_ARG;
     ctx->kernel = which;
     return PAGK_OK;
 }
@@ -883,7 +960,7 @@ int pagk_sync(pagk_ctx *ctx)
     if (!ctx) return PAGK_E_ARG;
     NOT_WHILE_CAPTURING(ctx, "pagk_sync");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PAGK_OK;
+    return lv_check(ctx);
 }
 
 int pagk_last_kernel_ms(pagk_ctx *ctx, float *track_ms, float *pyramid_ms)

@@ -117,16 +117,48 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
     b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
 }
 
-template <int NCH, bool LEAN = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
+// LEVELS (variant (f), "four features per wave, one LEVEL per wave"): the launch has n_levels x ceil(n / 4) waves and a
+// wave runs ONE pyramid level of its four features, a third of the lifetime of a whole-feature wave, so that a launch of
+// one to two rounds of resident waves does not end with the chip half empty behind a few long-lived waves.  Work items
+// are handed out by ticket counters in the order in which waves START: eight sequences (a.queue, 128 bytes apart -- one
+// counter serialises at ~23 ns per ticket, 1 ms for a 60000-feature launch), sequence x owning the quads q = x mod 8
+// and listing them level step by level step, coarsest level first; a wave starts with the sequence of its XCD and moves
+// on when a sequence is used up.  The item of step k of a quad takes over (p2x, p2y, iteration count) from the item of
+// step k - 1 through a.lv_state and waits for it on a.lv_done[quad]: that item has a lower ticket of the same sequence,
+// so it is held by a wave that has already started and itself waits only on lower tickets -- the chain ends at step 0,
+// which waits on nothing (no deadlock, whatever order the hardware dispatches workgroups in; as many waves as items, so
+// every wave finds one).  The wait is bounded all the same
+// (a.susp_polls looks, ~2 us apart): a wave that gives up raises a.lv_error (the host turns it into an error code) and
+// the launch drains.  Arithmetic per level and feature is k_track_quad's, so results are bit-identical.
+template <int NCH, bool LEAN = false, bool LEVELS = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
     __shared__ __attribute__((aligned(256))) QuadLds S;
     const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
+    int quad = (int)blockIdx.x, lv_step = 0;
+    if constexpr (LEVELS) {
+        const int nq = (a.n + 3) >> 2;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        quad = -1;
+        for (int k = 0; k < 8 && quad < 0; k++) {
+            const int x = (int)((xcc + k) & 7u);
+            const int cnt = (nq - x + 7) >> 3;  // quads of sequence x
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.queue + 32 * x, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t < cnt * a.n_levels) {
+                lv_step = t / cnt;
+                quad = 8 * (t - lv_step * cnt) + x;
+            }
+        }
+        if (quad < 0) return;  // (cannot happen: the launch has as many waves as there are items)
+    }
     // the kernel is instantiated per patch size (NCH = chunks of 64 pixels: 2 <-> h = 5, 4 <-> h = 7, 7 <-> h = 10): the
     // patch geometry is a compile-time constant (divisions by the patch width, LDS addresses, chunk lengths)
     constexpr int h = NCH == 7 ? 10 : (NCH == 4 ? 7 : 5), Wd = 2 * h + 1, P = Wd * Wd;
     static_assert(NCH == 2 || NCH == 4 || NCH == 7, "instantiated for h = 5, 7, 10");
-    const int raw = 4 * (int)blockIdx.x + row;
+    const int raw = 4 * quad + row;
     const int fi = raw < a.n ? raw : a.n - 1;  // rows past the end shadow the last feature and write nothing
     const bool live = raw < a.n && a.status_in[fi] != 0;
 
@@ -141,6 +173,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
     if (__ballot(live) == 0ull) {  // nothing to track in this wave (:173)
+        if (LEVELS && lv_step != a.n_levels - 1) return;  // (the quad's last item reports; nobody waits for the others)
         if (lr == 0 && raw < a.n) write_outputs(a, fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
         if (lane == 0 && a.iter_budget > 0) atomicAdd(a.susp_count + 2, 1);
         return;
@@ -163,6 +196,27 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     int succ = 1, iters = 0;
     float lastCost = 0.0f;
     bool susp = false;  // this row's feature was handed to k_track_resume (TrackArgs::iter_budget)
+    if constexpr (LEVELS) {
+        if (lv_step > 0) {  // take over from the item of the level above
+            // (agent-scope relaxed atomics on both sides, ordered by the wave's own instruction order -- the state is
+            // stored, the stores are waited for, then the flag is stored; the flag is seen, then the state is loaded.
+            // No fences: an acquire per look invalidates the CU's vector cache under the waves that are sampling
+            // (measured: 4000 features 1.7 ms instead of 0.39), a release per item writes back the XCD's L2)
+            int polls = 0;
+            while (ld_agent(a.lv_done + quad) < lv_step) {
+                if (++polls > a.susp_polls) {
+                    if (lane == 0) st_agent(a.lv_error, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(127);
+            }
+            const int *st = reinterpret_cast<const int *>(a.lv_state + 4 * (size_t)fi);
+            p2x = __int_as_float(ld_agent(st + 0)), p2y = __int_as_float(ld_agent(st + 1));
+            iters = ld_agent(st + 2);
+        }
+    }
+    const int level_first = LEVELS ? a.n_levels - 1 - lv_step : a.n_levels - 1;
+    const int level_last = LEVELS ? level_first : 0;
 #ifdef PAGK_STAMPS
     // diagnostic build only: cycles per phase of this wave -> a.dbg[16 * wave + k]: [0] level setup, [1] sampling,
     // [2] MFMA chain, [3] cost chain, [4] solve + update, [5] total, [6] wave-iterations
@@ -178,7 +232,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 #define QSTAMP(k)
 #endif
 
-    for (int level = a.n_levels - 1; level >= 0; level--) {
+    for (int level = level_first; level >= level_last; level--) {
         const DevLevel &L1 = a.l1[level];
         const DevLevel L2 = pin_level(a.l2[level]);
         const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
@@ -395,6 +449,17 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     }
 #endif
 #undef QSTAMP
+    if constexpr (LEVELS) {
+        if (level_last > 0) {  // hand the quad to the item of the next level: state, then the flag that publishes it
+            if (lr == 0 && raw < a.n) {
+                int *st = reinterpret_cast<int *>(a.lv_state + 4 * (size_t)fi);
+                st_agent(st + 0, __float_as_int(p2x)), st_agent(st + 1, __float_as_int(p2y)), st_agent(st + 2, iters);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the four rows' state has reached the coherence point
+            if (lane == 0) st_agent(a.lv_done + quad, lv_step + 1);
+            return;
+        }
+    }
     if (lr == 0 && raw < a.n && !susp) {
         if (live)
             write_outputs(a, fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)

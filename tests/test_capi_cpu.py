@@ -108,7 +108,7 @@ def test_context_setters_reject_a_null_context_and_bad_values(built):
         c = capi.Context(0)
         for bad in (0, -1, 65):
             assert c.lib.pagk_set_concurrency(c.h, bad) == capi.PAGK_E_ARG
-        for bad in (-1, 7):
+        for bad in (-1, 8):
             assert c.lib.pagk_set_kernel(c.h, bad) == capi.PAGK_E_ARG
         c.set_concurrency(8)
         c.set_concurrency(1)

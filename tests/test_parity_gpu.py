@@ -128,11 +128,35 @@ def test_rows_kernel_on_baseline_configs(ctx, idx, n):
     assert ctx.last_variant() == 6
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_level_kernel_matches_golden_vectors(ctx, name):
+    # four features per wave, ONE LEVEL per wave: levels x ceil(n / 4) waves, a quad handed from level to level through
+    # global memory (pagk_quad_kernel.h, LEVELS)
+    params, inp, exp = load_golden(name)
+    ctx.set_kernel(7)
+    try:
+        got = ctx.track(params, inp["img_ref"], inp["img_cur"], inp["pt_ref"], inp["pt_init"], inp["affine"],
+                        inp["status_in"])
+    finally:
+        ctx.set_kernel(0)
+    assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
+
+
+@pytest.mark.parametrize("idx,n", [(1, 1000), (1, 1001), (1, 1002), (1, 1003), (2, 2000), (3, 6000), (3, 20000)])
+def test_level_kernel_on_baseline_configs(ctx, idx, n):
+    # (config 2 has four levels; 20000 features are more waves than the device holds at once: items wait for waves
+    # that started earlier)
+    w = synth.config(idx, n=n)
+    got, ref = run_both(ctx, params_for(w), w, kernel=7)
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+    assert ctx.last_variant() == 7
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
 def test_quad_and_rows_kernels_with_fewer_features_than_rows(ctx, n):
     # a wave whose rows outnumber the features: spare rows shadow / idle and write nothing
     w = synth.config(1, n=n)
-    for kernel in (5, 6):
+    for kernel in (5, 6, 7):
         got, ref = run_both(ctx, params_for(w), w, kernel=kernel)
         assert_parity(got, ref, w.n, exact=True, what=f"kernel {kernel}, {n} features")
         assert ctx.last_variant() == kernel
