@@ -72,11 +72,14 @@ struct TrackArgs {
     int susp_polls;    // how often a finisher workgroup looks for its entry before it gives up (bounded: never a hang)
     // k_track_rows: the next feature index to hand out (zeroed before every launch); k_track_quad<.., LEVELS>: the ticket
     int *queue;
-    // k_track_quad<.., LEVELS>: lv_done[quad] = level steps finished (zeroed before every launch), lv_state[4 feature] =
-    // (p2x, p2y, iterations so far, -) handed from one level's wave to the next, lv_error: a wait ran out
-    int *lv_done;
+    // k_track_quad<.., LEVELS>: queue = eight sequences' counters, 32 ints apart ([0] tickets, [1 + k] quads that have
+    // finished level step k); lv_ready[(k * 8 + sequence) * ceil(quads / 8) + slot] = quad + 1, in the order in which the
+    // sequence's quads finished step k (all zeroed before every launch); lv_state[4 feature] = (p2x, p2y, iterations so
+    // far, -) handed from one level's wave to the next; lv_error: a wait ran out
+    int *lv_ready;
     float *lv_state;
     int *lv_error;
+    int lv_polls;      // looks (~3 us apart) a wave takes at its ready-list entry before it gives up (bounded: never a hang)
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)

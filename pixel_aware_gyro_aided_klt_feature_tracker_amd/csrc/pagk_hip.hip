@@ -55,7 +55,7 @@ struct pagk_ctx {
     int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
     size_t susp_bytes = 0;
-    void *lv = nullptr;       // one-level-per-wave launches: 8 ticket counters (1024 B) | int done[quads] | float state[4 n]
+    void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (1024 B) | ready lists | float state[4 n]
     size_t lv_bytes = 0;
     int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
     int *lv_error_dev = nullptr;  // ... as the device addresses it
@@ -65,6 +65,7 @@ struct pagk_ctx {
     int finisher_wgs = 16;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
     int finisher_polls = 20000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look: ~35 ms,
                                  // an order of magnitude beyond the longest launch the hand-over rule admits)
+    int level_polls = 30000;  // PAGK_LEVEL_POLLS: bounded wait of a one-level-per-wave item for its ready-list entry (~0.1 s)
     int quad_budget = -1;     // iterations a feature may run in the four-features-per-wave kernel before it is handed to
                               // the latency kernel; 0: never; -1 (default): chosen per launch, see quad_budget_for().
                               // PAGK_QUAD_BUDGET overrides.
@@ -84,10 +85,13 @@ struct pagk_ctx {
     // auto-selection thresholds, measured on MI355X at h = 10 (tools/sweep_n.py, profiles/r03_sweep_n.log): after round
     // 3's instruction diet the 4-wave DPP kernel is the fastest up to ~5000 features (it used to lose to the 2-wave MFMA
     // variant from 2500; that variant no longer wins at any size and is selected explicitly only), one wave per feature
-    // wins between ~5000 and ~7000, four features per wave from there.
+    // wins between ~5000 and ~7000, four features per wave from there.  Later in round 3: four features per wave with
+    // one pyramid level per wave (variant 7) is the fastest from ~6000 features for a context alone on the device
+    // (profiles/r03_levels_sweep.log); contexts that share the device (pagk_set_concurrency) keep the sequence above.
     int mfma_min_features = 0x7fffffff;  // PAGK_MFMA_MIN
     int wave_min_features = 5000;        // PAGK_WAVE_MIN
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
+    int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
@@ -333,6 +337,22 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
     return 20;
 }
 
+// The same for a one-level-per-wave launch (variant 7) of `quads` four-feature groups.  Its waves are short, so what
+// the hand-over removes is not an idle tail but the critical path itself: the launch cannot end before its slowest
+// feature has run its levels one after the other at the throughput kernel's ~11 us per iteration.  Measured with
+// budgets 0 / 14 / 20 / 26 (profiles/r03_levels_handover.log): 20 gains 30 % at 10000-12000 features of configs[3],
+// 13-20 % at 16000-24000, 3-7 % on the easier 752x480 pair, nothing from 30000 on (no loss either), and costs 3-6 %
+// at 6000; 14 hands over ten times as many features and loses everywhere.  On from 0.45 rounds of resident waves.
+int levels_budget_for(pagk_ctx *ctx, int quads, int iterations, int levels, int half)
+{
+    if (ctx->quad_budget >= 0) return ctx->quad_budget;
+    if (iterations * levels < 60 || ctx->concurrency != 1 || ctx->capturing) return 0;
+    if (100ll * quads <= 45ll * quad_capacity(ctx, half)) return 0;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    return 20;
+}
+
 int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
                  const float *d_pt_ref, const float *d_pt_init, const float *d_affine, const uint8_t *d_status,
                  const pagk_outputs *o, const PyrArgs *pyr = nullptr, int pyr_blocks = 0, bool *pyr_done = nullptr)
@@ -399,7 +419,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
         // four features per wave, one level per wave (needs more than one level to differ from the quad kernel)
-        const bool use_levels = mfma_ok && !a.calc_ncc && p->pyramids >= 2 && ctx->lv_error && ctx->kernel == 7;
+        const bool use_levels = mfma_ok && !a.calc_ncc && p->pyramids >= 2 && ctx->lv_error &&
+                                (ctx->kernel == 7 || (ctx->kernel == 0 && ctx->concurrency == 1 && n >= ctx->levels_min_features));
         const bool quad_like = ctx->kernel == 5 || ctx->kernel == 6 || ctx->kernel == 7;
         const bool use_quad = !use_rows && !use_levels && mfma_ok && !a.calc_ncc && (quad_like || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
         const bool use_wave = !use_quad && !use_rows && !use_levels && mfma_ok && (ctx->kernel == 3 || quad_like || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
@@ -446,14 +467,16 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_rows<4>);
             else if (a.half == 10) e = launch(k_track_rows<7>);
             HIPCHK(ctx, e);
-        } else if (use_levels) {
-            // pagk_quad_kernel.h, LEVELS: pyramids x ceil(n / 4) waves, each one level of four features
-            const int nch = (Pm + 63) / 64, nq = (n + 3) / 4, waves = nq * p->pyramids;
+        } else if (use_quad || use_levels) {
+            // four features per wave (pagk_quad_kernel.h): whole features per wave, or -- LEVELS -- one pyramid level per
+            // wave (pyramids x ceil(n / 4) waves)
+            const int nch = (Pm + 63) / 64, nq = (n + 3) / 4, waves = use_levels ? nq * p->pyramids : nq;
             const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
-            const size_t need_lv = 1024 + align_up((size_t)nq * 4, 256) + (size_t)n * 16;
+            const size_t ready_bytes = use_levels ? align_up((size_t)(p->pyramids - 1) * 8 * ((nq + 7) / 8) * 4, 256) : 0;
+            const size_t need_lv = use_levels ? 1024 + ready_bytes + (size_t)n * 16 : 0;
             if (need > ctx->quad_ws_bytes || need_lv > ctx->lv_bytes) {
                 if (ctx->capturing) {
-                    snprintf(ctx->err, sizeof(ctx->err), "the level kernel's workspace would have to be (re)allocated during graph capture");
+                    snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
                     return PAGK_E_ARG;
                 }
                 if (need > ctx->quad_ws_bytes) {
@@ -471,40 +494,20 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     ctx->lv_bytes = need_lv;
                 }
             }
-            uint8_t *lb = static_cast<uint8_t *>(ctx->lv);
             a.ws = static_cast<float *>(ctx->quad_ws);
-            a.queue = reinterpret_cast<int *>(lb);
-            a.lv_done = reinterpret_cast<int *>(lb + 1024);
-            a.lv_state = reinterpret_cast<float *>(lb + 1024 + align_up((size_t)nq * 4, 256));
-            a.lv_error = ctx->lv_error_dev;
             a.susp_polls = ctx->finisher_polls;
-            HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + (size_t)nq * 4, ctx->stream));  // tickets and flags
-            auto launch = [&](auto kern) -> hipError_t {
-                hipLaunchKernelGGL(kern, dim3(waves), dim3(64), 0, ctx->stream, a);
-                return hipGetLastError();
-            };
-            hipError_t e = hipErrorInvalidValue;
-            if (a.half == 5) e = lean ? launch(k_track_quad<2, true, true>) : launch(k_track_quad<2, false, true>);
-            else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true>) : launch(k_track_quad<4, false, true>);
-            else if (a.half == 10) e = lean ? launch(k_track_quad<7, true, true>) : launch(k_track_quad<7, false, true>);
-            HIPCHK(ctx, e);
-        } else if (use_quad) {
-            const int nch = (Pm + 63) / 64;
-            const size_t need = (size_t)((n + 3) / 4) * 4 * nch * 64 * sizeof(float);
-            if (need > ctx->quad_ws_bytes) {
-                if (ctx->capturing) {
-                    snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
-                    return PAGK_E_ARG;
-                }
-                if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
-                ctx->quad_ws = nullptr;
-                ctx->quad_ws_bytes = 0;
-                HIPCHK(ctx, hipMalloc(&ctx->quad_ws, need));
-                ctx->quad_ws_bytes = need;
+            if (use_levels) {
+                uint8_t *lb = static_cast<uint8_t *>(ctx->lv);
+                a.queue = reinterpret_cast<int *>(lb);
+                a.lv_ready = reinterpret_cast<int *>(lb + 1024);
+                a.lv_state = reinterpret_cast<float *>(lb + 1024 + ready_bytes);
+                a.lv_error = ctx->lv_error_dev;
+                a.lv_polls = ctx->level_polls;
+                HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + ready_bytes, ctx->stream));  // counters and ready lists
             }
-            a.ws = static_cast<float *>(ctx->quad_ws);
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
-            const int budget = quad_budget_for(ctx, (n + 3) / 4, p->iterations, p->pyramids, a.half);
+            const int budget = use_levels ? levels_budget_for(ctx, nq, p->iterations, p->pyramids, a.half)
+                                          : quad_budget_for(ctx, nq, p->iterations, p->pyramids, a.half);
             const bool handover = budget > 0;
             ctx->last_handover = handover;
             if (handover) {
@@ -525,8 +528,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_count = reinterpret_cast<int *>(sb);
                 a.susp_list = reinterpret_cast<int *>(sb + 256);
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
-                a.susp_waves = (n + 3) / 4;
-                a.susp_polls = ctx->finisher_polls;
+                a.susp_waves = waves;
                 a.susp_lone = ctx->susp_lone;
                 HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
             }
@@ -538,13 +540,19 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
             }
             auto launch = [&](auto kern) -> hipError_t {
-                hipLaunchKernelGGL(kern, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, a);
+                hipLaunchKernelGGL(kern, dim3(waves), dim3(64), 0, ctx->stream, a);
                 return hipGetLastError();
             };
             hipError_t e = hipErrorInvalidValue;
-            if (a.half == 5) e = lean ? launch(k_track_quad<2, true>) : launch(k_track_quad<2>);        // P = 121: 2 chunks of 64 pixels
-            else if (a.half == 7) e = lean ? launch(k_track_quad<4, true>) : launch(k_track_quad<4>);   // P = 225
-            else if (a.half == 10) e = lean ? launch(k_track_quad<7, true>) : launch(k_track_quad<7>);  // P = 441
+            if (use_levels) {
+                if (a.half == 5) e = lean ? launch(k_track_quad<2, true, true>) : launch(k_track_quad<2, false, true>);
+                else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true>) : launch(k_track_quad<4, false, true>);
+                else if (a.half == 10) e = lean ? launch(k_track_quad<7, true, true>) : launch(k_track_quad<7, false, true>);
+            } else {
+                if (a.half == 5) e = lean ? launch(k_track_quad<2, true>) : launch(k_track_quad<2>);        // P = 121: 2 chunks of 64 pixels
+                else if (a.half == 7) e = lean ? launch(k_track_quad<4, true>) : launch(k_track_quad<4>);   // P = 225
+                else if (a.half == 10) e = lean ? launch(k_track_quad<7, true>) : launch(k_track_quad<7>);  // P = 441
+            }
             HIPCHK(ctx, e);
             if (live) {
                 const size_t lds = track_block_lds_bytes(a.half);
@@ -866,11 +874,13 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
+    if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
     if (getenv("PAGK_ROWS_WAVES")) ctx->rows_waves_cap = atoi(getenv("PAGK_ROWS_WAVES"));
     if (getenv("PAGK_FINISHER_WGS")) ctx->finisher_wgs = atoi(getenv("PAGK_FINISHER_WGS"));
     if (getenv("PAGK_SUSPEND_LONE")) ctx->susp_lone = atoi(getenv("PAGK_SUSPEND_LONE"));
     if (getenv("PAGK_FINISHER_POLLS")) ctx->finisher_polls = atoi(getenv("PAGK_FINISHER_POLLS"));
+    if (getenv("PAGK_LEVEL_POLLS")) ctx->level_polls = atoi(getenv("PAGK_LEVEL_POLLS"));
     if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -117,31 +117,39 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
     b[0] = A[2], b[1] = A[6], b[2] = A[10], b[3] = A[14];
 }
 
-// LEVELS (variant (f), "four features per wave, one LEVEL per wave"): the launch has n_levels x ceil(n / 4) waves and a
-// wave runs ONE pyramid level of its four features, a third of the lifetime of a whole-feature wave, so that a launch of
-// one to two rounds of resident waves does not end with the chip half empty behind a few long-lived waves.  Work items
-// are handed out by ticket counters in the order in which waves START: eight sequences (a.queue, 128 bytes apart -- one
-// counter serialises at ~23 ns per ticket, 1 ms for a 60000-feature launch), sequence x owning the quads q = x mod 8
-// and listing them level step by level step, coarsest level first; a wave starts with the sequence of its XCD and moves
-// on when a sequence is used up.  The item of step k of a quad takes over (p2x, p2y, iteration count) from the item of
-// step k - 1 through a.lv_state and waits for it on a.lv_done[quad]: that item has a lower ticket of the same sequence,
-// so it is held by a wave that has already started and itself waits only on lower tickets -- the chain ends at step 0,
-// which waits on nothing (no deadlock, whatever order the hardware dispatches workgroups in; as many waves as items, so
-// every wave finds one).  The wait is bounded all the same
-// (a.susp_polls looks, ~2 us apart): a wave that gives up raises a.lv_error (the host turns it into an error code) and
-// the launch drains.  Arithmetic per level and feature is k_track_quad's, so results are bit-identical.
+// LEVELS (variant 7, "four features per wave, one LEVEL per wave"): the launch has n_levels x ceil(n / 4) waves and a
+// wave runs ONE pyramid level of four features, a third of the lifetime of a whole-feature wave, so that a launch of one
+// to a few rounds of resident waves does not end with the chip half empty behind a few long-lived waves.
+//   Work is handed out by ticket counters in the order in which waves START: eight sequences (a.queue, 128 bytes apart;
+// one counter would serialise at ~23 ns per ticket), sequence x owning the quads q = x mod 8; a wave starts with the
+// sequence of its XCD and moves on when a sequence is used up.  A sequence lists its work level step by level step,
+// coarsest level first.  Ticket j of step 0 IS quad 8 j + x.  Ticket j of step k > 0 is "the j-th quad of this
+// sequence to finish step k - 1": a wave that finishes a step appends its quad to the sequence's ready list of the next
+// step (a.lv_ready) after storing (p2x, p2y, iteration count) to a.lv_state, and the consumer waits for entry j of that
+// list -- not for a particular quad, so it waits only while the sequence really has nothing ready.  Every ticket of
+// step k - 1 is lower than every ticket of step k, so the waves that will produce the entries have started, and they
+// wait only on still lower steps: the chain ends at step 0, which waits on nothing (no deadlock, whatever order the
+// hardware dispatches workgroups in; as many waves as items, so every wave finds one).  The wait is bounded all the same
+// (a.lv_polls looks, ~3 us apart): a wave that gives up raises a.lv_error (the host turns it into an error code) and
+// the launch drains.  Both sides use agent-scope relaxed atomics ordered by the wave's own instruction order -- state
+// stored, stores waited for, entry stored; entry seen, state loaded.  No fences: an acquire per look invalidates the
+// CU's vector cache under the waves that are sampling (measured: 4000 features 1.7 ms instead of 0.33), a release per
+// item writes back the XCD's L2 (60000 features 2.8 ms instead of 1.5).  Arithmetic per level and feature is
+// k_track_quad's, so results are bit-identical.
 template <int NCH, bool LEAN = false, bool LEVELS = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
     __shared__ __attribute__((aligned(256))) QuadLds S;
     const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
     int quad = (int)blockIdx.x, lv_step = 0;
+    int lv_seq = 0;   // LEVELS: the sequence this wave's item belongs to
+    const int lv_cmax = LEVELS ? (((a.n + 3) >> 2) + 7) >> 3 : 0;  // ready-list slots per sequence and step
     if constexpr (LEVELS) {
         const int nq = (a.n + 3) >> 2;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        quad = -1;
-        for (int k = 0; k < 8 && quad < 0; k++) {
+        int j = -1;
+        for (int k = 0; k < 8 && j < 0; k++) {
             const int x = (int)((xcc + k) & 7u);
             const int cnt = (nq - x + 7) >> 3;  // quads of sequence x
             int t = 0;
@@ -149,11 +157,43 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             t = __builtin_amdgcn_readfirstlane(t);
             if (t < cnt * a.n_levels) {
                 lv_step = t / cnt;
-                quad = 8 * (t - lv_step * cnt) + x;
+                j = t - lv_step * cnt;
+                lv_seq = x;
             }
         }
-        if (quad < 0) return;  // (cannot happen: the launch has as many waves as there are items)
+        if (j < 0) return;  // (cannot happen: the launch has as many waves as there are items)
+        if (lv_step == 0) {
+            quad = 8 * j + lv_seq;
+        } else {  // the j-th quad of the sequence to have finished the level above
+            const int *entry = a.lv_ready + ((size_t)(lv_step - 1) * 8 + lv_seq) * lv_cmax + j;
+            int polls = 0, e;
+            while ((e = ld_agent(entry)) == 0) {
+                if (++polls > a.lv_polls) {
+                    if (lane == 0) st_agent(a.lv_error, 1);
+                    return;  // (results are void: the host reports the launch as failed)
+                }
+                __builtin_amdgcn_s_sleep(127);
+            }
+            quad = __builtin_amdgcn_readfirstlane(e) - 1;
+        }
     }
+    // LEVELS: this wave's quad is through with its level -- the next level's consumers may have it
+    auto lv_publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows' state has reached the coherence point
+        if (lane == 0) {
+            const int slot = atomicAdd(a.queue + 32 * lv_seq + 1 + lv_step, 1);
+            st_agent(a.lv_ready + ((size_t)lv_step * 8 + lv_seq) * lv_cmax + slot, quad + 1);
+        }
+    };
+    // hand-over: this wave hands nothing over from here on (the finishers stop waiting once every wave has said so; its
+    // list entries were stored with agent-scope atomics behind a fence of their own, this wave's instruction order does
+    // the rest: no release here -- it would write back the XCD's L2 once per wave)
+    auto wave_ended = [&]() {
+        if (a.iter_budget > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(a.susp_count + 2, 1);
+        }
+    };
     // the kernel is instantiated per patch size (NCH = chunks of 64 pixels: 2 <-> h = 5, 4 <-> h = 7, 7 <-> h = 10): the
     // patch geometry is a compile-time constant (divisions by the patch width, LDS addresses, chunk lengths)
     constexpr int h = NCH == 7 ? 10 : (NCH == 4 ? 7 : 5), Wd = 2 * h + 1, P = Wd * Wd;
@@ -173,9 +213,13 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
     if (__ballot(live) == 0ull) {  // nothing to track in this wave (:173)
-        if (LEVELS && lv_step != a.n_levels - 1) return;  // (the quad's last item reports; nobody waits for the others)
+        if (LEVELS && lv_step != a.n_levels - 1) {  // (the quad's last item reports)
+            lv_publish();
+            wave_ended();
+            return;
+        }
         if (lr == 0 && raw < a.n) write_outputs(a, fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
-        if (lane == 0 && a.iter_budget > 0) atomicAdd(a.susp_count + 2, 1);
+        wave_ended();
         return;
     }
 
@@ -198,21 +242,10 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     bool susp = false;  // this row's feature was handed to k_track_resume (TrackArgs::iter_budget)
     if constexpr (LEVELS) {
         if (lv_step > 0) {  // take over from the item of the level above
-            // (agent-scope relaxed atomics on both sides, ordered by the wave's own instruction order -- the state is
-            // stored, the stores are waited for, then the flag is stored; the flag is seen, then the state is loaded.
-            // No fences: an acquire per look invalidates the CU's vector cache under the waves that are sampling
-            // (measured: 4000 features 1.7 ms instead of 0.39), a release per item writes back the XCD's L2)
-            int polls = 0;
-            while (ld_agent(a.lv_done + quad) < lv_step) {
-                if (++polls > a.susp_polls) {
-                    if (lane == 0) st_agent(a.lv_error, 1);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(127);
-            }
             const int *st = reinterpret_cast<const int *>(a.lv_state + 4 * (size_t)fi);
             p2x = __int_as_float(ld_agent(st + 0)), p2y = __int_as_float(ld_agent(st + 1));
             iters = ld_agent(st + 2);
+            susp = ld_agent(st + 3) != 0;  // handed to the latency kernel on a level above
         }
     }
     const int level_first = LEVELS ? a.n_levels - 1 - lv_step : a.n_levels - 1;
@@ -450,13 +483,14 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 #endif
 #undef QSTAMP
     if constexpr (LEVELS) {
-        if (level_last > 0) {  // hand the quad to the item of the next level: state, then the flag that publishes it
+        if (level_last > 0) {  // hand the quad to the next level: state, then the ready-list entry that publishes it
             if (lr == 0 && raw < a.n) {
                 int *st = reinterpret_cast<int *>(a.lv_state + 4 * (size_t)fi);
                 st_agent(st + 0, __float_as_int(p2x)), st_agent(st + 1, __float_as_int(p2y)), st_agent(st + 2, iters);
+                st_agent(st + 3, susp ? 1 : 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the four rows' state has reached the coherence point
-            if (lane == 0) st_agent(a.lv_done + quad, lv_step + 1);
+            lv_publish();
+            wave_ended();
             return;
         }
     }
@@ -466,10 +500,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         else
             write_outputs(a, fi, init[2 * fi], init[2 * fi + 1], 0, 0.0f, 0, 0.0f, 0);
     }
-    if (a.iter_budget > 0) {  // this wave publishes nothing from here on (its entries are visible: fenced above)
-        __threadfence();
-        if (lane == 0) atomicAdd(a.susp_count + 2, 1);
-    }
+    wave_ended();
 }
 
 }  // namespace pagk

@@ -204,6 +204,25 @@ def test_quad_kernel_continuation(monkeypatch, budget, finisher):
             got, ref = run_both(c, params_for(w), w, kernel=5)
             assert_parity(got, ref, w.n, exact=True, what=f"{w.name} budget {budget}")
             assert c.last_variant() == 5
+            # the same through the one-level-per-wave form: a feature handed over on one level stays out of the waves
+            # of the levels below
+            got = run_both(c, params_for(w), w, kernel=7)[0]
+            assert_parity(got, ref, w.n, exact=True, what=f"{w.name} budget {budget}, one level per wave")
+            assert c.last_variant() == 7
+    finally:
+        c.close()
+
+
+def test_level_kernel_reports_a_wait_that_ran_out(monkeypatch):
+    # a wave that gives up waiting for the level above makes the launch fail loudly (never a hang, never silent)
+    monkeypatch.setenv("PAGK_LEVEL_POLLS", "0")
+    c = capi.Context(0)
+    try:
+        w = synth.config(1, n=6000)   # 4500 waves on 4096 slots: some consumers start before their entry is there
+        c.set_kernel(7)
+        with pytest.raises(capi.PagkError):
+            for _ in range(3):
+                c.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
     finally:
         c.close()
 
@@ -531,10 +550,10 @@ def test_config4_eight_concurrent_streams_on_one_gpu(ctx, hint, variant):
 
 
 def test_config3_direct_and_graph_steps_with_and_without_hand_over(ctx, monkeypatch):
-    """BASELINE configs[3] on one GPU: 5000 waves of the four-features-per-wave kernel are 1.2 rounds of resident
-    waves, so a direct launch hands features past the iteration budget to the latency kernel running beside it
-    (automatic rule, quad_budget_for); a captured graph does not (its branches replay one after the other), unless
-    forced -- then the finisher is a parallel branch of the graph (auxiliary stream joined through the fork event).
+    """BASELINE configs[3] on one GPU: the automatic choice is four features per wave, one level per wave (variant 7),
+    and a direct launch hands features past the iteration budget to the latency kernel running beside it (automatic
+    rule, levels_budget_for); a captured graph does not (its branches replay one after the other), unless forced --
+    then the finisher is a parallel branch of the graph (auxiliary stream joined through the fork event).
     All four ways give the same bits as the launch with the hand-over switched off."""
     w = synth.config(3)
     p = params_for(w)
@@ -557,15 +576,20 @@ def test_config3_direct_and_graph_steps_with_and_without_hand_over(ctx, monkeypa
             for _ in range(2):
                 out = rt.step(mode=mode)
             torch.cuda.synchronize()
-            assert rt.mode_used == mode and rt.ctx.last_variant() == 5
-            if mode == "serial":     # the rule: a direct launch of 1.2 rounds hands its stragglers over (max 62 iterations)
+            assert rt.mode_used == mode and rt.ctx.last_variant() == 7
+            if mode == "serial":     # the rule: a direct launch of this size hands its stragglers over (max 62 iterations)
                 assert 20 < rt.ctx.last_handover() < 0.05 * w.n
             assert_parity(distributed.to_numpy(out), ref, w.n, exact=True, what=f"configs[3] {mode} step, budget {forced or 'auto'}")
         rt.close()
 
 
 def test_hand_over_rule_by_launch_size(ctx):
-    # quad_budget_for: between 0.45 and 1.25 rounds of resident waves, alone on the device, iteration cap >= 60
+    # quad_budget_for: between 0.45 and 1.25 rounds of resident waves, alone on the device, iteration cap >= 60;
+    # levels_budget_for (one level per wave): from 0.45 rounds on
+    for n, expect in ((6000, False), (8000, True), (30000, True)):
+        w = synth.config(3, n=n)
+        ctx.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert ctx.last_variant() == 7 and (ctx.last_handover() > 0) == expect, n
     for n, expect in ((6000, False), (8000, True), (30000, False)):
         w = synth.config(3, n=n)
         ctx.set_kernel(5)
