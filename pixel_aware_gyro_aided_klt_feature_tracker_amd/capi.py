@@ -514,7 +514,8 @@ class Context:
     VARIANT_NAMES = {0: "4-wave workgroup per feature, DPP row chains", 1: "one thread per feature (cross-check)",
                      2: "2-wave workgroup per feature, f64 MFMA chain", 3: "one wave per feature, f64 MFMA chain",
                      4: "relaxed order (experiment)", 5: "four features per wave, f64 MFMA blocks",
-                     6: "four independent rows per wave + work queue"}
+                     6: "four independent rows per wave + work queue",
+                     7: "four features per wave, one pyramid level per wave"}
 
     def last_variant(self) -> int:
         return int(self.lib.pagk_last_variant(self.h))

@@ -4,7 +4,7 @@
 # Summaries: python tools/save_profile_variant.py <tag> for the variant tags, python tools/save_profile.py r03_bench.
 set -o pipefail
 mkdir -p gpurun_out/r03p
-SPECS=${PAGK_PROFILE_SPECS:-"r03_a_cfg1:1:1000:0 r03_b_cfg4:4:4000:2 r03_d_cfg3:3:20000:5 r03_d_cfg2x:2:2000:0"}
+SPECS=${PAGK_PROFILE_SPECS:-"r03_a_cfg1:1:1000:0 r03_b_cfg4:4:4000:2 r03_d_cfg3:3:20000:5 r03_f_cfg3:3:20000:7 r03_d_cfg2x:2:2000:0"}
 for spec in $SPECS; do
   spec=${spec//:/ }
   set -- $spec
