@@ -1,4 +1,4 @@
-"""Kernel time of the four-features-per-wave variant against (hand-over budget, live finisher workgroups), every setting
+"""Kernel time of the four-features-per-wave variant (PAGK_KERNEL=7: its one-level-per-wave form) against (hand-over budget, live finisher workgroups), every setting
 measured PAGK_REPS times in alternation (one process each): python tools/finisher_sweep.py [cfg:n ...]
 PAGK_SETTINGS="budget:wgs,..."  (budget 0 = no hand-over; wgs 0 = sweep only)."""
 import os, subprocess, sys
@@ -14,8 +14,8 @@ out = []
 for c in sys.argv[1:]:
     cfg, n = (int(v) for v in c.split(":"))
     w = synth.config(cfg, n=n)
-    ctx.set_kernel(5)
-    p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
+    ctx.set_kernel(int(os.environ.get("PAGK_KERNEL", "5")))
+    p = capi.make_params(half_patch=10, iterations=30, pyramids=w.pyramids, has_gyro=w.has_gyro, camera=w.camera)
     ts = []
     for _ in range(12):
         ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
