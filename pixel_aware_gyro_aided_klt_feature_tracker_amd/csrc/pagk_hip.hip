@@ -92,6 +92,7 @@ struct pagk_ctx {
     int wave_min_features = 5000;        // PAGK_WAVE_MIN
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
+    bool levels_shared = false;          // PAGK_LEVELS_SHARED=1 (measurement): ... also for contexts that share the device
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
 };
@@ -420,7 +421,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
         // four features per wave, one level per wave (needs more than one level to differ from the quad kernel)
         const bool use_levels = mfma_ok && !a.calc_ncc && p->pyramids >= 2 && ctx->lv_error &&
-                                (ctx->kernel == 7 || (ctx->kernel == 0 && ctx->concurrency == 1 && n >= ctx->levels_min_features));
+                                (ctx->kernel == 7 || (ctx->kernel == 0 && (ctx->concurrency == 1 || ctx->levels_shared) &&
+                                                      n_sel >= ctx->levels_min_features));
         const bool quad_like = ctx->kernel == 5 || ctx->kernel == 6 || ctx->kernel == 7;
         const bool use_quad = !use_rows && !use_levels && mfma_ok && !a.calc_ncc && (quad_like || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
         const bool use_wave = !use_quad && !use_rows && !use_levels && mfma_ok && (ctx->kernel == 3 || quad_like || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
@@ -875,6 +877,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
+    if (getenv("PAGK_LEVELS_SHARED")) ctx->levels_shared = atoi(getenv("PAGK_LEVELS_SHARED")) != 0;
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
     if (getenv("PAGK_ROWS_WAVES")) ctx->rows_waves_cap = atoi(getenv("PAGK_ROWS_WAVES"));
     if (getenv("PAGK_FINISHER_WGS")) ctx->finisher_wgs = atoi(getenv("PAGK_FINISHER_WGS"));
