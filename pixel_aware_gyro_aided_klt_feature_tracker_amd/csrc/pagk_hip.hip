@@ -344,13 +344,21 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
 // budgets 0 / 14 / 20 / 26 (profiles/r03_levels_handover.log): 20 gains 30 % at 10000-12000 features of configs[3],
 // 13-20 % at 16000-24000, 3-7 % on the easier 752x480 pair, nothing from 30000 on (no loss either), and costs 3-6 %
 // at 6000; 14 hands over ten times as many features and loses everywhere.  On from 0.45 rounds of resident waves.
-int levels_budget_for(pagk_ctx *ctx, int quads, int iterations, int levels, int half)
+// Inside a graph capture (the replayed graph runs a finisher branch AFTER the throughput kernel) the hand-over is
+// the sweep alone -- `*live` false: the stragglers leave the throughput waves early and are finished by the 4-wave
+// kernel behind them.  That still pays while the launch is chain-bound (12000 features of configs[3] 577 us instead of
+// 714, 20000 features 699 instead of 769) and costs from about 1.3 rounds on (30000 features: +7.5 %,
+// profiles/r03_levels_sweep_only.log): in a capture, up to 1.25 rounds.
+int levels_budget_for(pagk_ctx *ctx, int quads, int iterations, int levels, int half, bool *live)
 {
-    if (ctx->quad_budget >= 0) return ctx->quad_budget;
-    if (iterations * levels < 60 || ctx->concurrency != 1 || ctx->capturing) return 0;
-    if (100ll * quads <= 45ll * quad_capacity(ctx, half)) return 0;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    const bool in_capture = ctx->capturing || hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+    *live = !in_capture || ctx->quad_budget >= 0;   // (a forced budget keeps the parallel branch: tests)
+    if (ctx->quad_budget >= 0) return ctx->quad_budget;
+    if (iterations * levels < 60 || ctx->concurrency != 1) return 0;
+    const long long cap = quad_capacity(ctx, half);
+    if (100ll * quads <= 45 * cap) return 0;
+    if (in_capture && 100ll * quads > 125 * cap) return 0;
     return 20;
 }
 
@@ -508,7 +516,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + ready_bytes, ctx->stream));  // counters and ready lists
             }
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
-            const int budget = use_levels ? levels_budget_for(ctx, nq, p->iterations, p->pyramids, a.half)
+            bool live_ok = true;
+            const int budget = use_levels ? levels_budget_for(ctx, nq, p->iterations, p->pyramids, a.half, &live_ok)
                                           : quad_budget_for(ctx, nq, p->iterations, p->pyramids, a.half);
             const bool handover = budget > 0;
             ctx->last_handover = handover;
@@ -536,7 +545,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             }
             // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (inside a graph
             // capture the auxiliary stream joins the capture through the fork event: a parallel branch of the graph)
-            const bool live = handover && ctx->finisher_wgs > 0 && ctx->aux_stream;
+            const bool live = handover && live_ok && ctx->finisher_wgs > 0 && ctx->aux_stream;
             if (live) {
                 HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
