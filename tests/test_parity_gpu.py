@@ -213,6 +213,23 @@ def test_quad_kernel_continuation(monkeypatch, budget, finisher):
         c.close()
 
 
+def test_level_kernel_alternating_workloads_on_one_context(ctx):
+    # the level-to-level hand-off goes through buffers that every launch reuses (ready lists, per-feature state, the
+    # workspace): two different workloads of the same shape, alternated on one context, so that nothing a launch reads
+    # can be a leftover of the launch before it that happens to have the right value
+    ws = [synth.config(3, n=9000, seed=0x5EED1000 + k) for k in range(2)]
+    refs = [orc.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16) for w in ws]
+    ctx.set_kernel(7)
+    try:
+        for rep in range(3):
+            for w, ref in zip(ws, refs):
+                got = ctx.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+                assert ctx.last_variant() == 7
+                assert_parity(got, ref, w.n, exact=True, what=f"{w.name} repeat {rep}")
+    finally:
+        ctx.set_kernel(0)
+
+
 def test_level_kernel_reports_a_wait_that_ran_out(monkeypatch):
     # a wave that gives up waiting for the level above makes the launch fail loudly (never a hang, never silent)
     monkeypatch.setenv("PAGK_LEVEL_POLLS", "0")
