@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
 #ifdef PAGK_STAMPS
     if (tid == 0 && a.dbg) {
         // resumed features: after the throughput kernel's per-wave records
-        unsigned long long *dbgp = a.dbg + (resume ? (size_t)16 * ((a.n + 3) / 4) : 0);
+        unsigned long long *dbgp = a.dbg + (resume ? (size_t)16 * (a.susp_waves > 0 ? a.susp_waves : (a.n + 3) / 4) : 0);
         st[5] = __builtin_amdgcn_s_memtime() - t_begin;
         for (int k = 0; k < 6; k++) dbgp[(size_t)i * 16 + k] = st[k];
         dbgp[(size_t)i * 16 + 6] = (unsigned long long)iters;

@@ -9,11 +9,11 @@ from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
 capi.LIB_PATH = os.environ.get("PAGK_STAMPS_LIB") or os.path.join(ROOT, "tools", "bin", "libpagk_hip_stamps.so")
 n, cfg = int(os.environ.get("PAGK_N", "20000")), int(os.environ.get("PAGK_CFG", "3"))
 w = synth.config(cfg, n=n)
-nw = (w.n + 3) // 4
+kern = int(os.environ.get("PAGK_KERNEL", "5"))   # 5: k_track_quad, 7: its one-level-per-wave form, 6: k_track_rows (timeline only)
+nw = (w.n + 3) // 4 * (3 if kern == 7 else 1)   # wave records; a finisher's per-feature records follow them
 dbg = torch.zeros((nw + w.n) * 16, dtype=torch.int64, device="cuda")
 os.environ["PAGK_DBG_PTR"] = str(dbg.data_ptr())
 ctx = capi.Context(0)
-kern = int(os.environ.get("PAGK_KERNEL", "5"))   # 5: k_track_quad, 6: k_track_rows (timeline only)
 ctx.set_kernel(kern)
 p = capi.make_params(half_patch=10, iterations=30, pyramids=3, has_gyro=w.has_gyro, camera=w.camera)
 for _ in range(2):
@@ -29,7 +29,7 @@ it = out["iters"][:w.n]
 print(f"cfg{cfg} n={w.n}: kernel {trk*1e3:.1f} us (stamped build), {len(d)} waves, wave-iterations mean {wi.mean():.1f} "
       f"(features: mean {it[w.status_in > 0].mean():.1f} iterations)")
 names = ["level setup", "sampling", "MFMA chain", "cost chain", "solve+update", "total"]
-for k in range(6 if kern == 5 else 0):   # k_track_rows records the timeline only
+for k in range(6 if kern in (5, 7) else 0):   # k_track_rows records the timeline only
     per = d[:, k] / (wi if k in (1, 2, 3, 4) else 1)
     print(f"  {names[k]:13s}: {100 * d[:, k].sum() / d[:, 5].sum():5.1f} %  mean {d[:, k].mean():10.0f} cycles/wave"
           + (f"  {per.mean():8.0f} cycles per wave-iteration" if k in (1, 2, 3, 4) else ""))
