@@ -347,8 +347,14 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 float x, y;
                 patch_xy(c, x, y);
                 const bool valid = 64 * c + lane < P;
-                auto issue = [&](int f, FiveTaps &tp) {
+                auto issue = [&](int f, FiveTaps &tp, float &s1v) {
                     const int src = 16 * f;
+#ifndef PAGK_EXPERIMENT_RECOMPUTE_I1
+                    // the feature's img1 sample of this pixel first: loads return in order, so it is there when the taps are
+                    s1v = ws[(f * NCH + c) * 64];
+#else
+                    s1v = sample<true>(L1, rl(ptx, src) + x, rl(pty, src) + y);
+#endif
                     float wx = x, wy = y;
                     if (a.use_affine) {  // :203-204
                         wx = rl(A00, src) * x + rl(A01, src) * y;
@@ -362,24 +368,8 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 // Two named tap sets alternate and every consume sits on its own control path: a copy "cur = nxt" or a
                 // consume shared by the paths with / without a following issue would each make the compiler wait
                 // for ALL outstanding loads (s_waitcnt vmcnt(0)) -- the pipelining would exist in the source only.
-                // the img1 samples of the chunk come first, all four features: loads return in order, so these are never
-                // waited for together with taps in flight (a register holding a pending load, paired by the allocator
-                // with a live weight in a packed operand, costs a wait for everything issued before it)
-                float s1q[4];
-#ifdef PAGK_EXPERIMENT_RECOMPUTE_I1
-                // EXPERIMENT (never the product): the img1 sample of every pixel re-derived in every iteration (one more
-                // tap and interpolation per sampled pixel) instead of the per-wave global workspace written once per level
-                // -- VERDICT r2 item 2's question "does the workspace round trip cost time against recomputation":
-                // profiles/r03_quad_i1_workspace_vs_recompute.log.
-#pragma unroll
-                for (int f = 0; f < 4; f++) s1q[f] = sample<true>(L1, rl(ptx, 16 * f) + x, rl(pty, 16 * f) + y);
-#else
-#pragma unroll
-                for (int f = 0; f < 4; f++) s1q[f] = ws[(f * NCH + c) * 64];
-#endif
-                auto consume = [&](int f, const FiveTaps &tp) {
+                auto consume = [&](int f, const FiveTaps &tp, const float s1v) {
                     const int src = 16 * f;
-                    const float s1v = f == 0 ? s1q[0] : f == 1 ? s1q[1] : f == 2 ? s1q[2] : s1q[3];
                     const Five s = sample5_finish(tp);
                     const float e = s.c + rl(db, src) - rl(gain, src) * s1v;  // :252-253
                     const float Ix = 0.5f * (s.xp - s.xm);                     // :259-260
@@ -394,15 +384,16 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                 int fa = first_of(actm), fb = 0;
                 unsigned long long rest = without(actm, fa);
                 FiveTaps ta, tb;
+                float s1a, s1b;
                 bool last_in_a = true;
-                issue(fa, ta);
+                issue(fa, ta, s1a);
 #pragma nounroll
                 while (rest) {  // a next feature exists: its gathers go out before the current taps are consumed
                     fb = first_of(rest);
                     rest = without(rest, fb);
-                    issue(fb, tb);
+                    issue(fb, tb, s1b);
                     __builtin_amdgcn_sched_barrier(0);
-                    consume(fa, ta);
+                    consume(fa, ta, s1a);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!rest) {
                         last_in_a = false;
@@ -410,19 +401,19 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     }
                     fa = first_of(rest);
                     rest = without(rest, fa);
-                    issue(fa, ta);
+                    issue(fa, ta, s1a);
                     __builtin_amdgcn_sched_barrier(0);
-                    consume(fb, tb);
+                    consume(fb, tb, s1b);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the last feature of the chunk: nothing is in flight behind it (kept apart from the consumes in the
                 // loop: a shared copy would have to wait as if nothing were in flight there either)
                 if (last_in_a) {
                     asm volatile("; last taps: set a");
-                    consume(fa, ta);
+                    consume(fa, ta, s1a);
                 } else {
                     asm volatile("; last taps: set b");
-                    consume(fb, tb);
+                    consume(fb, tb, s1b);
                 }
                 if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
