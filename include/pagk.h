@@ -177,10 +177,13 @@ int pagk_sync(pagk_ctx *ctx);
  * context's own; pass NULL to restore. */
 int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
 
-/* Kernel selection.  0 = automatic (default): by launch size, one of
- *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < ~2500 features)
+/* Kernel selection.  0 = automatic (default): by launch size (thresholds measured on MI355X at half_patch 10), one of
+ *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < 5000 features)
+ *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; 5000 to 5999 features, and calculate_ncc launches)
+ *   - four features per wavefront, one pyramid level per wavefront  (= 7; from 6000 features, context alone on the device)
+ *   - four features per wavefront  (= 5; from 7000 features in total when pagk_set_concurrency says the device is shared)
+ * Selected explicitly only:
  *   - 2-wave workgroup per feature, ordered accumulation as a v_mfma_f64_4x4x4f64 chain  (= 2)
- *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; highest throughput, >= ~10000 features)
  * 1 = reference-shaped one-thread-per-feature kernel (debug / cross-check).  2 and 3 force a variant
  * (half_patch 5, 7 or 10; other sizes fall back to the 4-wave kernel).  Every variant 0-3 produces
  * bit-identical results.
