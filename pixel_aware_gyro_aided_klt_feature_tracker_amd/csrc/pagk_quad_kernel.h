@@ -125,7 +125,8 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
 // sequence of its XCD and moves on when a sequence is used up.  A sequence lists its work level step by level step,
 // coarsest level first.  Ticket j of step 0 IS quad 8 j + x.  Ticket j of step k > 0 is "the j-th quad of this
 // sequence to finish step k - 1": a wave that finishes a step appends its quad to the sequence's ready list of the next
-// step (a.lv_ready) after storing (p2x, p2y, iteration count) to a.lv_state, and the consumer waits for entry j of that
+// step (a.lv_ready) after storing (p2x, p2y, iteration count, handed-over flag) per feature to a.lv_state, and the
+// consumer waits for entry j of that
 // list -- not for a particular quad, so it waits only while the sequence really has nothing ready.  Every ticket of
 // step k - 1 is lower than every ticket of step k, so the waves that will produce the entries have started, and they
 // wait only on still lower steps: the chain ends at step 0, which waits on nothing (no deadlock, whatever order the
