@@ -65,7 +65,7 @@ struct pagk_ctx {
     int finisher_wgs = 16;    // PAGK_FINISHER_WGS: workgroups of the live finisher (0: sweep only)
     int finisher_polls = 20000;  // PAGK_FINISHER_POLLS: bounded wait of a finisher workgroup (~2 us per look: ~35 ms,
                                  // an order of magnitude beyond the longest launch the hand-over rule admits)
-    int level_polls = 30000;  // PAGK_LEVEL_POLLS: bounded wait of a one-level-per-wave item for its ready-list entry (~0.1 s)
+    int level_polls = 300000;  // PAGK_LEVEL_POLLS: bounded wait of a one-level-per-wave item for its ready-list entry (~1 s: far beyond any launch, also on a time-sliced device)
     int quad_budget = -1;     // iterations a feature may run in the four-features-per-wave kernel before it is handed to
                               // the latency kernel; 0: never; -1 (default): chosen per launch, see quad_budget_for().
                               // PAGK_QUAD_BUDGET overrides.
