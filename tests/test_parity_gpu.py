@@ -213,6 +213,18 @@ def test_quad_kernel_continuation(monkeypatch, budget, finisher):
         c.close()
 
 
+@pytest.mark.parametrize("h,L,n,penalty", [(5, 4, 50001, False), (7, 2, 30011, False), (10, 5, 9001, True), (5, 3, 7, False)])
+def test_level_kernel_shapes(ctx, h, L, n, penalty):
+    # the other patch sizes, 2 to 5 levels, quad counts that are no multiple of the eight ticket sequences, far more
+    # waves than resident slots (50001 features x 4 levels = 50004 waves), the generic (penalty) instantiation,
+    # fewer quads than sequences
+    w = synth.make_workload(f"lv-h{h}-L{L}", 1280, 720, n, seed=0x5EED0300 + h * 16 + L, half_patch=h, iterations=30,
+                            pyramids=L, camera=synth.D435I, penalty=penalty)
+    got, ref = run_both(ctx, params_for(w), w, kernel=7)
+    assert ctx.last_variant() == 7
+    assert_parity(got, ref, w.n, exact=True, what=w.name)
+
+
 def test_level_kernel_alternating_workloads_on_one_context(ctx):
     # the level-to-level hand-off goes through buffers that every launch reuses (ready lists, per-feature state, the
     # workspace): two different workloads of the same shape, alternated on one context, so that nothing a launch reads
