@@ -79,6 +79,7 @@ struct TrackArgs {
     int *lv_ready;
     float *lv_state;
     int *lv_error;
+    int lv_shift;      // test knob: a wave starts with the sequence of XCD (its own + lv_shift) mod 8 -- every hand-off then crosses XCDs
     int lv_polls;      // looks (~3 us apart) a wave takes at its ready-list entry before it gives up (bounded: never a hang)
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;

@@ -92,6 +92,7 @@ struct pagk_ctx {
     int wave_min_features = 5000;        // PAGK_WAVE_MIN
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
+    int levels_shift = 0;                // PAGK_LEVELS_XCD_SHIFT (tests): waves start with another XCD's ticket sequence
     bool levels_shared = false;          // PAGK_LEVELS_SHARED=1 (measurement): ... also for contexts that share the device
     bool unfused_pyramid = false;  // PAGK_UNFUSED_PYRAMID=1: level-by-level launches (cross-check)
     char err[256] = {0};
@@ -513,6 +514,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.lv_state = reinterpret_cast<float *>(lb + 1024 + ready_bytes);
                 a.lv_error = ctx->lv_error_dev;
                 a.lv_polls = ctx->level_polls;
+                a.lv_shift = ctx->levels_shift;
                 HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + ready_bytes, ctx->stream));  // counters and ready lists
             }
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
@@ -886,6 +888,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
+    if (getenv("PAGK_LEVELS_XCD_SHIFT")) ctx->levels_shift = atoi(getenv("PAGK_LEVELS_XCD_SHIFT")) & 7;
     if (getenv("PAGK_LEVELS_SHARED")) ctx->levels_shared = atoi(getenv("PAGK_LEVELS_SHARED")) != 0;
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
     if (getenv("PAGK_ROWS_WAVES")) ctx->rows_waves_cap = atoi(getenv("PAGK_ROWS_WAVES"));

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         int j = -1;
         for (int k = 0; k < 8 && j < 0; k++) {
-            const int x = (int)((xcc + k) & 7u);
+            const int x = (int)((xcc + (unsigned)a.lv_shift + k) & 7u);
             const int cnt = (nq - x + 7) >> 3;  // quads of sequence x
             int t = 0;
             if (lane == 0) t = atomicAdd(a.queue + 32 * x, 1);

@@ -242,6 +242,26 @@ def test_level_kernel_alternating_workloads_on_one_context(ctx):
         ctx.set_kernel(0)
 
 
+@pytest.mark.parametrize("shift", [1, 4])
+def test_level_kernel_hand_offs_across_xcds(monkeypatch, shift):
+    # by default a wave takes its work from the ticket sequence of its own XCD, so most level-to-level hand-offs stay
+    # inside one XCD's L2; with the test knob every wave serves ANOTHER XCD's sequence: producer and consumer of a
+    # hand-off sit on different XCDs (different L2s), launch after launch with different data
+    monkeypatch.setenv("PAGK_LEVELS_XCD_SHIFT", str(shift))
+    c = capi.Context(0)
+    try:
+        ws = [synth.config(3, n=9000, seed=0x5EED2000 + k) for k in range(2)] + [synth.config(1, n=7001, seed=0x5EED2100)]
+        refs = [orc.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16) for w in ws]
+        c.set_kernel(7)
+        for rep in range(2):
+            for w, ref in zip(ws, refs):
+                got = c.track(params_for(w), w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+                assert c.last_variant() == 7
+                assert_parity(got, ref, w.n, exact=True, what=f"{w.name} shift {shift} repeat {rep}")
+    finally:
+        c.close()
+
+
 def test_level_kernel_reports_a_wait_that_ran_out(monkeypatch):
     # a wave that gives up waiting for the level above makes the launch fail loudly (never a hang, never silent)
     monkeypatch.setenv("PAGK_LEVEL_POLLS", "0")
