@@ -67,6 +67,7 @@ def test_bench_line_contract():
     assert b["vs_baseline"] is None and b["n_gpus"] == 1 and b["steps"] == 8 and b["warmup"] == 3
     assert b["scaling"] == "weak" and b["higher_is_better"] is True and b["data"] == "synthetic"
     assert "workload" in b["config"] and "model" not in b["config"]
+    assert 0.0 <= b["spinup_s"] <= 2.0   # the untimed spin-up before the W warm-up steps is disclosed in the line
     rf = b["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
