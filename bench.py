@@ -330,12 +330,22 @@ def main() -> int:
     # step is replayed for a fixed wall time first (synchronised every 20 steps: a deep launch backlog has its own
     # after-effect), THEN the W warm-up steps and the K timed steps follow exactly as the contract says.
     spinup_s = float(os.environ.get("PAGK_BENCH_SPINUP_S", "0.5"))
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < spinup_s:
-        for _ in range(20):
-            rt.step(mode=step_mode)
-        rt.finish()
-        torch.cuda.synchronize()
+    if spinup_s > 0:
+        def burst(k):
+            for _ in range(k):
+                rt.step(mode=step_mode)
+            rt.finish()
+            torch.cuda.synchronize()
+        t_spin = time.perf_counter()
+        burst(20)
+        # the number of bursts is agreed between the ranks: a step of the sharded mode contains a collective
+        bursts = int(min(1000, max(1, spinup_s / max(time.perf_counter() - t_spin, 1e-6))))
+        if world > 1:
+            t = torch.tensor([bursts], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bursts = int(t.item())
+        for _ in range(bursts):
+            burst(20)
     elapsed, out = time_steps(rt, args.steps, args.warmup, step_mode, barrier)
     per_gpu_ms = [elapsed / args.steps * 1e3]
     if world > 1:
