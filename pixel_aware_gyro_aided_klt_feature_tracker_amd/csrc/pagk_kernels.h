@@ -1120,6 +1120,16 @@ __global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
     track_block_body<NR, TAIL, WAVES, MFMA, RELAXED, LEAN>(a, (int)blockIdx.x);
 }
 
+// The same 4-wave kernel compiled for FIVE waves per SIMD (96 VGPRs, 13 spilled at h = 10): five workgroups per CU
+// instead of four.  For launches of several rounds of workgroups (2500 features and more), where the launch is
+// throughput-bound: -2.5 % at 3000 features, -3 % at 4000, -3.5 % at 5000; nothing at 2000, and at 1000 (all features
+// resident at four per CU) the spills would only cost (profiles/r03_ab23_five_workgroups_per_cu.log).
+template <int NR, int TAIL, bool LEAN = false>
+__global__ void __launch_bounds__(256, 5) k_track_block5(TrackArgs a)
+{
+    track_block_body<NR, TAIL, 4, false, false, LEAN>(a, (int)blockIdx.x);
+}
+
 // The latency kernel as the second pass of a large launch: finishes the features a throughput kernel suspended
 // (TrackArgs::iter_budget).  A fixed grid walks the list; *susp_count is read on the device, so the launch is the
 // same whatever the count (graph-capturable).
