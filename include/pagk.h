@@ -178,8 +178,9 @@ int pagk_sync(pagk_ctx *ctx);
 int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
 
 /* Kernel selection.  0 = automatic (default): by launch size (thresholds measured on MI355X at half_patch 10), one of
- *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < 5000 features)
- *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; 5000 to 5999 features, and calculate_ncc launches)
+ *   - 4-wave workgroup per feature, DPP-row ordered accumulation  (lowest latency; < 6000 features)
+ *   - one wavefront per feature, f32 streams + MFMA chain  (= 3; calculate_ncc launches from 6000 features, and 6000 to
+ *     6999 features in total when the device is shared)
  *   - four features per wavefront, one pyramid level per wavefront  (= 7; from 6000 features, context alone on the device)
  *   - four features per wavefront  (= 5; from 7000 features in total when pagk_set_concurrency says the device is shared)
  * Selected explicitly only:

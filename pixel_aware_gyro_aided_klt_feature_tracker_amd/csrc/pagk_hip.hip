@@ -89,7 +89,7 @@ struct pagk_ctx {
     // one pyramid level per wave (variant 7) is the fastest from ~6000 features for a context alone on the device
     // (profiles/r03_levels_sweep.log); contexts that share the device (pagk_set_concurrency) keep the sequence above.
     int mfma_min_features = 0x7fffffff;  // PAGK_MFMA_MIN
-    int wave_min_features = 5000;        // PAGK_WAVE_MIN
+    int wave_min_features = 6000;        // PAGK_WAVE_MIN (5000 until the 4-wave kernel had its build for five workgroups per CU)
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int block5_min_features = 2500;      // PAGK_BLOCK5_MIN: the 4-wave kernel in its five-workgroups-per-CU build (h = 10)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
