@@ -161,10 +161,13 @@ def config_row(cfg_idx: int, n: int, device: int, steps: int, streams: int = 1) 
     # gains nothing from the replay, and only a direct launch runs the straggler finisher beside the kernel)
     times = {}
     for mode in ("graph", "serial"):
-        for _ in range(3):
-            for rt in cams:
-                out = rt.step(mode=mode)
-        torch.cuda.synchronize()
+        # (the same kind of spin-up as the headline's, shorter: the first steps after a pause run slow)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.15:
+            for _ in range(3):
+                for rt in cams:
+                    out = rt.step(mode=mode)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             for rt in cams:
@@ -185,8 +188,7 @@ def config_row(cfg_idx: int, n: int, device: int, steps: int, streams: int = 1) 
            "ms_per_step_by_mode": {k: v * 1e3 for k, v in times.items()},
            "mean_iters": float(it[w.status_in > 0].mean()), "max_iters": int(it.max()),
            "variant": capi.Context.VARIANT_NAMES.get(cams[0].ctx.last_variant(), "?"),
-           # features the throughput kernel handed to the latency kernel in the last direct launch (0: rule not applied;
-           # the hand-over never runs inside a replayed graph, so a row whose step_mode is "graph" did not use it)
+           # features the throughput kernel handed to the latency kernel in the last direct launch (0: rule not applied)
            "handover": int(cams[0].ctx.last_handover()),
            "kernel_ms": kms, "pyramid_ms": pms,
            "roofline_frac": w.n_active * b_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
