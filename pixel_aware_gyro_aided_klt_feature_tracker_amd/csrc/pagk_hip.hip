@@ -887,6 +887,15 @@ int pagk_create(pagk_ctx **out, int device)
             }
         }
     }
+    // the selection thresholds were measured on 256 CUs; they are launch sizes relative to what the device holds at once,
+    // so a device (or a partition of one) with another CU count gets them in proportion
+    if (ctx->cus > 0 && ctx->cus != 256) {
+        auto scaled = [&](int v) { return v >= 0x7fffffff / 2 ? v : (int)((long long)v * ctx->cus / 256); };
+        ctx->wave_min_features = scaled(ctx->wave_min_features);
+        ctx->quad_min_features = scaled(ctx->quad_min_features);
+        ctx->levels_min_features = scaled(ctx->levels_min_features);
+        ctx->block5_min_features = scaled(ctx->block5_min_features);
+    }
     ctx->unfused_pyramid = getenv("PAGK_UNFUSED_PYRAMID") != nullptr;
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
