@@ -55,7 +55,7 @@ struct pagk_ctx {
     int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
     size_t susp_bytes = 0;
-    void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (1024 B) | ready lists | float state[4 n]
+    void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (8 x 4096 B) | ready lists | float state[4 n]
     size_t lv_bytes = 0;
     int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
     int *lv_error_dev = nullptr;  // ... as the device addresses it
@@ -485,7 +485,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             const int nch = (Pm + 63) / 64, nq = (n + 3) / 4, waves = use_levels ? nq * p->pyramids : nq;
             const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
             const size_t ready_bytes = use_levels ? align_up((size_t)(p->pyramids - 1) * 8 * ((nq + 7) / 8) * 4, 256) : 0;
-            const size_t need_lv = use_levels ? 1024 + ready_bytes + (size_t)n * 16 : 0;
+            const size_t need_lv = use_levels ? 32768 + ready_bytes + (size_t)n * 16 : 0;
             if (need > ctx->quad_ws_bytes || need_lv > ctx->lv_bytes) {
                 if (ctx->capturing) {
                     snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
@@ -511,12 +511,12 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             if (use_levels) {
                 uint8_t *lb = static_cast<uint8_t *>(ctx->lv);
                 a.queue = reinterpret_cast<int *>(lb);
-                a.lv_ready = reinterpret_cast<int *>(lb + 1024);
-                a.lv_state = reinterpret_cast<float *>(lb + 1024 + ready_bytes);
+                a.lv_ready = reinterpret_cast<int *>(lb + 32768);
+                a.lv_state = reinterpret_cast<float *>(lb + 32768 + ready_bytes);
                 a.lv_error = ctx->lv_error_dev;
                 a.lv_polls = ctx->level_polls;
                 a.lv_shift = ctx->levels_shift;
-                HIPCHK(ctx, hipMemsetAsync(lb, 0, 1024 + ready_bytes, ctx->stream));  // counters and ready lists
+                HIPCHK(ctx, hipMemsetAsync(lb, 0, 32768 + ready_bytes, ctx->stream));  // counters and ready lists
             }
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
             bool live_ok = true;
