@@ -72,8 +72,8 @@ struct TrackArgs {
     int susp_polls;    // how often a finisher workgroup looks for its entry before it gives up (bounded: never a hang)
     // k_track_rows: the next feature index to hand out (zeroed before every launch); k_track_quad<.., LEVELS>: the ticket
     int *queue;
-    // k_track_quad<.., LEVELS>: queue = eight sequences' counters, 1024 ints apart ([0] tickets, [1 + k] quads that have
-    // finished level step k); lv_ready[(k * 8 + sequence) * ceil(quads / 8) + slot] = quad + 1, in the order in which the
+    // k_track_quad<.., LEVELS>: queue = eight sequences' counters, 1024 ints apart ([0] tickets, [64 (1 + k)] quads that
+    // have finished level step k: a cache line each); lv_ready[(k * 8 + sequence) * ceil(quads / 8) + slot] = quad + 1, in the order in which the
     // sequence's quads finished step k (all zeroed before every launch); lv_state[4 feature] = (p2x, p2y, iterations so
     // far, -) handed from one level's wave to the next; lv_error: a wait ran out
     int *lv_ready;

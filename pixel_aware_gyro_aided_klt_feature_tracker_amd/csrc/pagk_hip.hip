@@ -542,7 +542,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_count = reinterpret_cast<int *>(sb);
                 a.susp_list = reinterpret_cast<int *>(sb + 256);
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
-                a.susp_waves = waves;
+                a.susp_waves = nq;   // the waves that report their end: all of them, or -- one level per wave -- a quad's last
                 a.susp_lone = ctx->susp_lone;
                 HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
             }
@@ -568,10 +568,14 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 else if (a.half == 10) e = lean ? launch(k_track_quad<7, true>) : launch(k_track_quad<7>);  // P = 441
             }
             HIPCHK(ctx, e);
+            TrackArgs af = a;   // what the latency kernels get
+#ifdef PAGK_STAMPS
+            if (af.dbg) af.dbg += (size_t)16 * (waves - nq);  // (diagnostic build: their records follow the throughput waves')
+#endif
             if (live) {
                 const size_t lds = track_block_lds_bytes(a.half);
                 auto finisher = [&](auto kern) -> hipError_t {
-                    hipLaunchKernelGGL(kern, dim3(ctx->finisher_wgs), dim3(kBlock), lds, ctx->aux_stream, a);
+                    hipLaunchKernelGGL(kern, dim3(ctx->finisher_wgs), dim3(kBlock), lds, ctx->aux_stream, af);
                     return hipGetLastError();
                 };
                 if (a.half == 5) e = lean ? finisher(k_track_resume_live<1, 25, true>) : finisher(k_track_resume_live<1, 25>);
@@ -586,7 +590,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 const size_t lds = track_block_lds_bytes(a.half);
                 const int grid = live ? 64 : (n < 1024 ? n : 1024);
                 auto resume = [&](auto kern) -> hipError_t {
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, a);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, ctx->stream, af);
                     return hipGetLastError();
                 };
                 if (a.half == 5) e = lean ? resume(k_track_resume<1, 25, true>) : resume(k_track_resume<1, 25>);

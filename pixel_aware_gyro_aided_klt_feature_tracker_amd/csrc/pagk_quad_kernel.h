@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     auto lv_publish = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows' state has reached the coherence point
         if (lane == 0) {
-            const int slot = atomicAdd(a.queue + kLvSeqStride * lv_seq + 1 + lv_step, 1);
+            const int slot = atomicAdd(a.queue + kLvSeqStride * lv_seq + 64 * (1 + lv_step), 1);
             st_agent(a.lv_ready + ((size_t)lv_step * 8 + lv_seq) * lv_cmax + slot, quad + 1);
         }
     };
@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     // list entries were stored with agent-scope atomics behind a fence of their own, this wave's instruction order does
     // the rest: no release here -- it would write back the XCD's L2 once per wave)
     auto wave_ended = [&]() {
+        // (LEVELS: only the wave of a quad's LAST level reports -- the waves of its other levels ended before that one
+        // started; a third of the atomics on the one counter every wave of the launch shares)
+        if (LEVELS && lv_step != a.n_levels - 1) return;
         if (a.iter_budget > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) atomicAdd(a.susp_count + 2, 1);
