@@ -55,6 +55,7 @@ struct pagk_ctx {
     int rows_waves_cap = 0;            // PAGK_ROWS_WAVES: upper bound of that grid (tests: a small grid, a long queue)
     void *susp = nullptr;     // continuation buffers: int count (256 B) | int list[n] | SuspState state[n]
     size_t susp_bytes = 0;
+    int *susp_count_dev = nullptr;  // the hand-over count of the last launch that used one (in `susp` or in `lv`)
     void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (8 x 4096 B) | ready lists | float state[4 n]
     size_t lv_bytes = 0;
     int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
@@ -485,7 +486,10 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             const int nch = (Pm + 63) / 64, nq = (n + 3) / 4, waves = use_levels ? nq * p->pyramids : nq;
             const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
             const size_t ready_bytes = use_levels ? align_up((size_t)(p->pyramids - 1) * 8 * ((nq + 7) / 8) * 4, 256) : 0;
-            const size_t need_lv = use_levels ? 32768 + ready_bytes + (size_t)n * 16 : 0;
+            // one-level-per-wave launches keep everything that must be zero before the launch in ONE block (one memset):
+            // counters | ready lists | hand-over count | hand-over list; then the two state arrays
+            const size_t susp_zero = 256 + align_up((size_t)n * 4, 256);
+            const size_t need_lv = use_levels ? 32768 + ready_bytes + susp_zero + (size_t)n * 16 + (size_t)n * sizeof(SuspState) : 0;
             if (need > ctx->quad_ws_bytes || need_lv > ctx->lv_bytes) {
                 if (ctx->capturing) {
                     snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
@@ -512,11 +516,10 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 uint8_t *lb = static_cast<uint8_t *>(ctx->lv);
                 a.queue = reinterpret_cast<int *>(lb);
                 a.lv_ready = reinterpret_cast<int *>(lb + 32768);
-                a.lv_state = reinterpret_cast<float *>(lb + 32768 + ready_bytes);
+                a.lv_state = reinterpret_cast<float *>(lb + 32768 + ready_bytes + susp_zero);
                 a.lv_error = ctx->lv_error_dev;
                 a.lv_polls = ctx->level_polls;
                 a.lv_shift = ctx->levels_shift;
-                HIPCHK(ctx, hipMemsetAsync(lb, 0, 32768 + ready_bytes, ctx->stream));  // counters and ready lists
             }
             // continuation buffers; the hand-over needs the 4-wave kernel's LDS (<= 48 KB at these patch sizes)
             bool live_ok = true;
@@ -524,7 +527,19 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                                           : quad_budget_for(ctx, nq, p->iterations, p->pyramids, a.half);
             const bool handover = budget > 0;
             ctx->last_handover = handover;
-            if (handover) {
+            if (use_levels) {
+                uint8_t *lb = static_cast<uint8_t *>(ctx->lv), *sb = lb + 32768 + ready_bytes;
+                if (handover) {
+                    a.iter_budget = budget;
+                    a.susp_count = reinterpret_cast<int *>(sb);
+                    a.susp_list = reinterpret_cast<int *>(sb + 256);
+                    a.susp_state = reinterpret_cast<SuspState *>(sb + susp_zero + (size_t)n * 16);
+                    a.susp_waves = nq;   // the waves that report their end: a quad's last-level wave
+                    a.susp_lone = ctx->susp_lone;
+                    ctx->susp_count_dev = a.susp_count;
+                }
+                HIPCHK(ctx, hipMemsetAsync(lb, 0, 32768 + ready_bytes + (handover ? 256 + (size_t)n * 4 : 0), ctx->stream));
+            } else if (handover) {
                 const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
                 if (need_s > ctx->susp_bytes) {
                     if (ctx->capturing) {
@@ -542,8 +557,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 a.susp_count = reinterpret_cast<int *>(sb);
                 a.susp_list = reinterpret_cast<int *>(sb + 256);
                 a.susp_state = reinterpret_cast<SuspState *>(sb + 256 + align_up((size_t)n * 4, 256));
-                a.susp_waves = nq;   // the waves that report their end: all of them, or -- one level per wave -- a quad's last
+                a.susp_waves = nq;   // the waves that report their end: all of them
                 a.susp_lone = ctx->susp_lone;
+                ctx->susp_count_dev = a.susp_count;
                 HIPCHK(ctx, hipMemsetAsync(sb, 0, 256 + (size_t)n * 4, ctx->stream));  // counters and list
             }
             // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (inside a graph
@@ -983,10 +999,10 @@ int pagk_last_variant(const pagk_ctx *ctx) { return ctx ? ctx->last_variant : PA
 int pagk_last_handover(pagk_ctx *ctx)
 {
     if (!ctx) return PAGK_E_ARG;
-    if (!ctx->last_handover || !ctx->susp) return 0;
+    if (!ctx->last_handover || !ctx->susp_count_dev) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int count = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&count, ctx->susp, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&count, ctx->susp_count_dev, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return count;
 }
