@@ -225,6 +225,31 @@ def test_level_kernel_shapes(ctx, h, L, n, penalty):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
+def test_level_kernel_with_features_switched_off(ctx):
+    # quads without a live feature pass through every level (their waves publish them and leave), whole blocks of them
+    # and all of them; a quad with one live row among switched-off ones
+    w = synth.config(1, n=6403)
+    p = params_for(w)
+    rng = np.random.default_rng(11)
+    for kind in ("all", "blocks", "sparse"):
+        st = w.status_in.copy()
+        if kind == "all":
+            st[:] = 0
+        elif kind == "blocks":
+            st[1000:3000] = 0
+            st[5000:] = 0
+        else:
+            st[rng.random(w.n) < 0.7] = 0
+        ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, st, nthreads=16)
+        ctx.set_kernel(7)
+        try:
+            got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, st)
+            assert ctx.last_variant() == 7
+        finally:
+            ctx.set_kernel(0)
+        assert_parity(got, ref, w.n, exact=True, what=f"features switched off: {kind}")
+
+
 def test_level_kernel_alternating_workloads_on_one_context(ctx):
     # the level-to-level hand-off goes through buffers that every launch reuses (ready lists, per-feature state, the
     # workspace): two different workloads of the same shape, alternated on one context, so that nothing a launch reads
