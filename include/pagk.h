@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 202 /* 0.2.2 */
+#define PAGK_VERSION 203 /* 0.2.3: solver_variant, pagk_frame_upload_pinned, kernel 7 */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
