@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 203 /* 0.2.3: solver_variant, pagk_frame_upload_pinned, kernel 7 */
+#define PAGK_VERSION 300 /* 0.3.0: pipelined 4-wave kernel, pagk_selftest_repeat_sum */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -267,6 +267,12 @@ int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const doub
                          double *q_prepared, double *root, double *root_lean);
 int pagk_selftest_solve(pagk_ctx *ctx, int32_t n, const double *H, const double *b, uint32_t solver_variant,
                         double *x_serial, double *norm_serial, double *x_lanes, double *nsq_lanes);
+/* pagk_selftest_repeat_sum: H(2,2) of src/patch_match.cpp:296 is the ordered sum of `count` = (2h+1)^2 copies of c * c
+ * (J[2] = de_dg = c is constant over the patch, :263).  The pipelined 4-wave kernel (half_patch 8, 9, 10) computes it in
+ * closed form -- binade by binade, ~100 instructions -- instead of as a `count`-step chain; per item i this returns the
+ * closed form (closed[i]) beside the loop s = fma(c, c, s) (loop[i]) for the caller's c[i].  57 < count <= 480.
+ * Host pointers. */
+int pagk_selftest_repeat_sum(pagk_ctx *ctx, int32_t n, const float *c, int32_t count, double *closed, double *loop);
 
 /* hipGraph capture of the per-frame work (BASELINE configs[4], "hipGraph-captured iterate").  A camera
  * stream issues the same launches on the same device pointers every frame; between pagk_graph_begin and

@@ -208,6 +208,9 @@ def declare(lib) -> None:
         lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         lib.pagk_selftest_solve.restype = C.c_int
         lib.pagk_selftest_solve.argtypes = [vp, i32, vp, vp, C.c_uint32, vp, vp, vp, vp]
+    if hasattr(lib, "pagk_selftest_repeat_sum"):
+        lib.pagk_selftest_repeat_sum.restype = C.c_int
+        lib.pagk_selftest_repeat_sum.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.pagk_match_features.restype = C.c_int
     lib.pagk_match_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     # the sharded path
@@ -249,6 +252,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
+    "pagk_selftest_repeat_sum",
 ]
 
 
@@ -467,6 +471,15 @@ class Context:
         self._check(self.lib.pagk_selftest_divide(self.h, n, _ptr(num), _ptr(den), _ptr(qp), _ptr(qq), _ptr(rt), _ptr(rl)),
                     "pagk_selftest_divide")
         return qp[:n], qq[:n], rt[:n], rl[:n]
+
+    def selftest_repeat_sum(self, c: np.ndarray, count: int):
+        """(closed form, loop) of the ordered sum of `count` copies of c*c on the device (pagk_selftest_repeat_sum)."""
+        c = np.ascontiguousarray(c, dtype=np.float32)
+        n = c.shape[0]
+        closed, loop = np.empty(n, np.float64), np.empty(n, np.float64)
+        self._check(self.lib.pagk_selftest_repeat_sum(self.h, n, _ptr(c), int(count), _ptr(closed), _ptr(loop)),
+                    "pagk_selftest_repeat_sum")
+        return closed, loop
 
     def selftest_solve(self, H: np.ndarray, b: np.ndarray, solver_variant: int = 0):
         """H.llt().solve(b) and the update's norm for n 4x4 systems: (x, norm) of the one-lane form and

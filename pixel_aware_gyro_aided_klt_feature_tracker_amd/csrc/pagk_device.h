@@ -679,7 +679,7 @@ __device__ __forceinline__ double llt4_solve_norm(const double (&M)[4][4], const
 // The same solve spread over four lanes (l = 0..3 of one wave, all holding the same H and b): per
 // Cholesky column the divides of the rows below the pivot and the forward-substitution divide of that
 // column are ONE divide executed by four lanes instead of up to four sequences in one lane;
-// results travel by v_readlane.  Operation for operation the arithmetic of llt4_solve_nsq_form above.
+// results travel by DPP row broadcasts.  Operation for operation the arithmetic of llt4_solve_nsq_form above.
 __device__ __forceinline__ double lane_bcast(double v, int src)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -687,11 +687,31 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
     hi = __builtin_amdgcn_readlane(hi, src);
     return __hiloint2double(hi, lo);
 }
+// The same for a source lane K < 16 of the caller's own 16-lane row: ONE v_mov_b64_dpp row_newbcast:K instead of two
+// v_readlane and two v_mov back from the scalar registers (round 4: the solve's nine broadcasts cost it 36 of its ~240
+// instructions, and a lone wave pays ~7 cycles per instruction of any kind).  The four solving lanes are lanes 0..3 of
+// their wave in every kernel, i.e. of row 0.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v)
+{
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, false);  // row_newbcast:K
+}
 
 #ifdef PAGK_COUNT_REDO
 static __device__ uint32_t g_redo_lo, g_redo_hi;   // (diagnostic build: racy by design, last writer wins)
 #endif
-template <bool FAST>
+// ROWB: the lane-to-lane results travel by row_bcast (one DPP instruction, the value stays in a vector register) instead
+// of lane_bcast (two v_readlane, the value in scalar registers): fewer instructions, ~20 more live VGPRs -- for kernels
+// that have them (the pipelined 4-wave kernel; the others sit at their register limit and would spill).
+template <int K, bool ROWB>
+__device__ __forceinline__ double solve_bcast(double v)
+{
+    if constexpr (ROWB)
+        return row_bcast<K>(v);
+    else
+        return lane_bcast(v, K);
+}
+template <bool FAST, bool ROWB = false>
 __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4][4], const double (&b)[4], int l,
                                                             double (&x)[4], uint32_t sv, OperandRange &rg)
 {
@@ -713,8 +733,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     const double n0 = l == 0 ? b[0] : (l == 1 ? H10 : (l == 2 ? H20 : H30));
     const double q0 = column(n0, D0, l == 0);
     const double own0 = (l == 0 || ok0) ? q0 : n0;
-    double r0 = lane_bcast(own0, 0);
-    const double L10 = lane_bcast(own0, 1), L20 = lane_bcast(own0, 2), L30 = lane_bcast(own0, 3);
+    double r0 = solve_bcast<0, ROWB>(own0);
+    const double L10 = solve_bcast<1, ROWB>(own0), L20 = solve_bcast<2, ROWB>(own0), L30 = solve_bcast<3, ROWB>(own0);
     // column 1: lane 1 -> r1, lanes 2, 3 -> L(i,1)
     const double x1 = H11 - L10 * L10;
     const bool ok1 = FAST || (ok0 && !(x1 <= 0.0));
@@ -724,8 +744,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     const double n1 = l == 1 ? b[1] - L10 * r0 : h1 - (l == 2 ? L20 : L30) * L10;
     const double q1 = column(n1, D1, l == 1);
     const double own1 = (l == 1 || ok1) ? q1 : h1;
-    double r1 = lane_bcast(own1, 1);
-    const double L21 = lane_bcast(own1, 2), L31 = lane_bcast(own1, 3);
+    double r1 = solve_bcast<1, ROWB>(own1);
+    const double L21 = solve_bcast<2, ROWB>(own1), L31 = solve_bcast<3, ROWB>(own1);
     // column 2: lane 2 -> r2, lane 3 -> L(3,2)
     double s = L20 * L20;
     s += L21 * L21;
@@ -738,8 +758,8 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
     const double n2 = l == 2 ? b[2] - (L20 * r0 + L21 * r1) : H32 - s;
     const double q2 = column(n2, D2, l == 2);
     const double own2 = (l == 2 || ok2) ? q2 : H32;
-    double r2 = lane_bcast(own2, 2);
-    const double L32 = lane_bcast(own2, 3);
+    double r2 = solve_bcast<2, ROWB>(own2);
+    const double L32 = solve_bcast<3, ROWB>(own2);
     // column 3
     const double a0 = L30 * L30, a1 = L31 * L31, a2 = L32 * L32;
     const double x3 = H33 - ((sv & SV_PIVOT_TREE) ? a0 + (a1 + a2) : (a0 + a1) + a2);
@@ -754,13 +774,14 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes_form(const double (&M)[4]
 
 // (the calling lanes -- four, or a whole wave whose lanes 0..3 matter -- take the decision together: the form
 // broadcasts between them)
+template <bool ROWB = false>
 __device__ __forceinline__ double llt4_solve_nsq_lanes(const double (&M)[4][4], const double (&b)[4], int l,
                                                        double (&x)[4], uint32_t sv)
 {
     OperandRange rg;
-    double nsq = llt4_solve_nsq_lanes_form<true>(M, b, l, x, sv, rg);
+    double nsq = llt4_solve_nsq_lanes_form<true, ROWB>(M, b, l, x, sv, rg);
 #ifndef PAGK_EXPERIMENT_NO_REDO
-    if (__builtin_amdgcn_ballot_w64(!rg.in_range() && l < 4) != 0) nsq = llt4_solve_nsq_lanes_form<false>(M, b, l, x, sv, rg);
+    if (__builtin_amdgcn_ballot_w64(!rg.in_range() && l < 4) != 0) nsq = llt4_solve_nsq_lanes_form<false, ROWB>(M, b, l, x, sv, rg);
 #endif
 #ifdef PAGK_COUNT_REDO
     g_redo_lo = rg.t;
@@ -768,10 +789,54 @@ __device__ __forceinline__ double llt4_solve_nsq_lanes(const double (&M)[4][4], 
     return nsq;
 }
 
+// H22 = the ordered sum of P copies of q = c * c (src/patch_match.cpp:296 with J[2] = de_dg = c constant over the patch,
+// :263): s_0 = 0, s_k = RN(s_{k-1} + q).  The value depends on the level only, and it needs no 441-step chain: q is the
+// exact product of two floats (48 significant bits), so
+//   - the first 32 partial sums are exact (k q < 2^6 q needs at most 53 bits): s_32 = 32 q;
+//   - while s stays inside one binade [2^F, 2^(F+1)) every step adds the same increment I_F = q rounded to that binade's
+//     spacing u -- s is a multiple of u, so RN(s + q) = s + RN_u(q); a tie (q mod u == u/2) goes to the even multiple,
+//     which after ONE step inside the binade is again "s + the same I_F" (s / u is even from then on) -- and
+//     I_F = (q + 1.5 * 2^F) - 1.5 * 2^F is that rounding done by the adder itself;
+//   - so per binade: n steps at once as fma(n, I_F, s) (exact: the result is a multiple of u below 2^(F+1)), with n
+//     chosen to stop at least one increment short of the binade's top, then four plain steps that carry s across the
+//     top and once more inside the next binade (the parity step).  32 q lies in binade E + 5, P q < 2^(E+10): five
+//     binades, and the step count is made to come out at exactly P by capping n.
+// Bit-identical to the loop for every float c (tests/test_repeat_sum.py: all 2^23 mantissas x P = 289 / 361 / 441 on the
+// host, with the quotient estimate perturbed both ways; pagk_selftest_repeat_sum on the device).  ~100 instructions
+// instead of a 441-step dependent chain.  P in (57, 480].
+__device__ __forceinline__ double repeat_sum_f64(double q, int P)
+{
+    if (!(q > 0.0)) return (double)P * q;  // c == 0: every partial sum is 0
+    double x = 32.0 * q;
+    int k = 32;
+    double top = __hiloint2double((__double2hiint(q) & 0x7ff00000) + (6 << 20), 0);  // 2^(E+6)
+    double M = 0.75 * top;                                                             // 1.5 * 2^(E+5)
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        const double I = (q + M) - M;
+        const float est = (float)(top - x) * __builtin_amdgcn_rcpf((float)I);
+        int n = (int)est - 1;
+        const int lim = (P - k) - 4 * (5 - b);
+        n = n > lim ? lim : n;
+        n = n < 0 ? 0 : n;
+        x = __builtin_fma((double)n, I, x);
+        k += n + 4;
+        x = x + q;
+        x = x + q;
+        x = x + q;
+        x = x + q;
+        M *= 2.0;
+        top *= 2.0;
+    }
+    return x;
+}
+
 // Gyro regularisation penalty, src/patch_match.cpp:302-314.  Adds to H (lower triangle
 // only: LLT reads nothing else), b and cost.
-__device__ __forceinline__ void add_penalty(const TrackArgs &a, float dx, float dy, double (&H)[4][4],
-                                            double (&b)[4], float &cost)
+// add_penalty_hb: the H and b terms; returns e_pen * e_pen, which the caller adds to the cost (:313) -- the pipelined
+// 4-wave kernel solves before its cost chain has finished.
+__device__ __forceinline__ double add_penalty_hb(const TrackArgs &a, float dx, float dy, double (&H)[4][4],
+                                                 double (&b)[4])
 {
     double d = (double)sqrtf(dx * dx + dy * dy);                                       // :304
     double e_pen = (double)a.lam_invlog * soft_log((double)a.alpha * d + 1);           // :305
@@ -793,7 +858,13 @@ __device__ __forceinline__ void add_penalty(const TrackArgs &a, float dx, float 
     b[1] += jy * e_pen;
     b[2] += 0.0 * e_pen;
     b[3] += 0.0 * e_pen;
-    cost = (float)((double)cost + e_pen * e_pen);                                      // :313
+    return e_pen * e_pen;
+}
+__device__ __forceinline__ void add_penalty(const TrackArgs &a, float dx, float dy, double (&H)[4][4],
+                                            double (&b)[4], float &cost)
+{
+    const double epsq = add_penalty_hb(a, dx, dy, H, b);
+    cost = (float)((double)cost + epsq);                                               // :313
 }
 
 // DistortVecPoints, src/utils.cpp:49-76, one point.

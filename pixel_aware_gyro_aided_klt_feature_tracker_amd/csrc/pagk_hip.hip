@@ -391,7 +391,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.dist_pred = o->dist_pred;
     a.ncc = o->ncc;
     a.iters = o->iters;
-#if defined(PAGK_STAMPS) || defined(PAGK_COUNT_REDO)
+#if defined(PAGK_STAMPS) || defined(PAGK_COUNT_REDO) || defined(PAGK_TIC)
     a.dbg = reinterpret_cast<unsigned long long *>(getenv("PAGK_DBG_PTR") ? strtoull(getenv("PAGK_DBG_PTR"), nullptr, 0) : 0ull);
 #endif
     a.half = p->half_patch;
@@ -1722,6 +1722,27 @@ int pagk_selftest_divide(pagk_ctx *ctx, int32_t n, const double *num, const doub
     HIPCHK(ctx, hipMemcpyAsync(q_prepared, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(root, d + 4 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(root_lean, d + 5 * (size_t)n, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAGK_OK;
+}
+
+int pagk_selftest_repeat_sum(pagk_ctx *ctx, int32_t n, const float *c, int32_t count, double *closed, double *loop)
+{
+    if (!ctx || n < 0 || count <= 57 || count > 480) return PAGK_E_ARG;
+    NOT_WHILE_CAPTURING(ctx, "pagk_selftest_repeat_sum");
+    if (n == 0) return PAGK_OK;
+    if (!c || !closed || !loop) return PAGK_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch s;
+    const size_t nn = (size_t)n;
+    HIPCHK(ctx, hipMalloc(&s.p, nn * (2 * sizeof(double) + sizeof(float))));
+    double *d_closed = static_cast<double *>(s.p), *d_loop = d_closed + nn;
+    float *d_c = reinterpret_cast<float *>(d_loop + nn);
+    HIPCHK(ctx, hipMemcpyAsync(d_c, c, nn * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_repeat_sum, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_c, count, d_closed, d_loop);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(closed, d_closed, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(loop, d_loop, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PAGK_OK;
 }

@@ -431,6 +431,7 @@ __host__ __device__ inline size_t track_block_lds_bytes(int half)
 {
     size_t PP = (size_t)track_block_pp(half);
     size_t bytes = kStreams * (PP + 1) * 8 + PP * 4 + 2 * 8 + 16 * 8 + 5 * 8 + 2 * 4 + 8;  // streams PP + 1 doubles apart
+    bytes += 16 + 16 + 8;  // the pipelined body (pagk_pipe_kernel.h): int flags[4], double h22[2], double pen
 #ifdef PAGK_EXPERIMENT_LDS_WINDOW
     bytes += 32 * 32 * 4;  // the staged img2 window (experiment build only, see track_block_body)
 #endif
@@ -449,6 +450,10 @@ __device__ __forceinline__ uint32_t lds_off(const void *p)
 {
     return (uint32_t)(uintptr_t)p;  // low half of a flat LDS address = offset in the LDS aperture
 }
+
+}  // namespace pagk
+#include "pagk_pipe_kernel.h"
+namespace pagk {
 
 // ---- relaxed-order accumulation (EXPERIMENT, pagk_set_kernel(ctx, 4)) -----------------------------
 // What the reference's summation order costs: the same kernel with the 441-step ordered chains replaced by
@@ -510,7 +515,9 @@ __device__ __forceinline__ float relaxed_row_f32(const float *arr, int P, int lr
 // defaults, BASELINE's configs): both become compile-time facts.  A lone wave pays ~6 cycles per instruction, and the
 // generic form spends ~55 of the solve's ~390 on them -- the selects of the five association switches, the Eigen <= 3.2
 // reciprocal path computed beside the division, and twenty register copies where the penalty's branch rejoins.
-template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false, bool LEAN = false>
+// PIPE: two-round patches (h = 8, 9, 10) run the pipelined iteration of pagk_pipe_kernel.h; false keeps the serial
+// phases below (the five-workgroups-per-CU build: at 96 VGPRs the pipelined body spills 32 registers instead of 13).
+template <int NR, int TAIL, int WAVES = 4, bool MFMA = false, bool RELAXED = false, bool LEAN = false, bool PIPE = true>
 __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i, const SuspState *resume = nullptr)
 {
     static_assert(MFMA ? WAVES == 2 : WAVES == 4, "DPP rows need 4 waves; the MFMA variant is 2 waves");
@@ -518,12 +525,20 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     constexpr int kBlock = WAVES * 64;
     constexpr int kStreams = MFMA ? 3 : 8;
     constexpr int kAcc = MFMA ? 24 : 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
     // two-round patches: (NR, TAIL) determine the patch size (h = 8, 9, 10 <-> P mod 32 = 1, 9, 25), so every LDS
     // address below is a compile-time constant (immediate offsets instead of address registers)
     constexpr int HC = (NR == 2 && !MFMA) ? (TAIL == 1 ? 8 : (TAIL == 9 ? 9 : 10)) : 0;
+#ifndef PAGK_NO_PIPE
+    // ... and their iteration is the pipelined one (pagk_pipe_kernel.h; -DPAGK_NO_PIPE builds the serial phases below
+    // for A/B runs: the same bits)
+    if constexpr (HC != 0 && !RELAXED && PIPE) {
+        track_pipe_body<HC, LEAN>(a, i, resume);
+        return;
+    }
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int h = HC ? HC : a.half, Wd = 2 * h + 1, P = Wd * Wd, PP = track_block_pp(h);
     const int nfull = P / 32;  // P mod 32 == TAIL
 
@@ -1127,7 +1142,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4) k_track_block(TrackArgs a)
 template <int NR, int TAIL, bool LEAN = false>
 __global__ void __launch_bounds__(256, 5) k_track_block5(TrackArgs a)
 {
-    track_block_body<NR, TAIL, 4, false, false, LEAN>(a, (int)blockIdx.x);
+    track_block_body<NR, TAIL, 4, false, false, LEAN, false>(a, (int)blockIdx.x);
 }
 
 // The latency kernel as the second pass of a large launch: finishes the features a throughput kernel suspended

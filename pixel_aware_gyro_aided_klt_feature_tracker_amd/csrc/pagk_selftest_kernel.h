@@ -12,6 +12,19 @@
 
 namespace pagk {
 
+// H22 of the pipelined 4-wave kernel: the ordered sum of P copies of c * c in closed form (repeat_sum_f64) beside the
+// P-step loop it replaces (src/patch_match.cpp:296 with J[2] = c).
+__global__ void __launch_bounds__(256) k_selftest_repeat_sum(int n, const float *c, int P, double *closed, double *loop)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double cd = (double)c[i];
+    closed[i] = repeat_sum_f64(cd * cd, P);
+    double s = 0.0;
+    for (int k = 0; k < P; k++) s = __builtin_fma(cd, cd, s);
+    loop[i] = s;
+}
+
 __global__ void __launch_bounds__(256) k_selftest_divide(int n, const double *num, const double *den, double *q_plain,
                                                          double *q_prepared, double *root, double *root_lean)
 {
