@@ -25,6 +25,7 @@
 // of its wave at the level boundary (its block / row keeps accumulating values nobody reads).  Results are
 // bit-identical to the oracle and to the other variants (tests/test_parity_gpu.py).
 #pragma once
+#include <cstddef>
 #include "pagk_chain_asm.h"
 #include "pagk_device.h"
 
@@ -37,17 +38,29 @@ __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p
                                               float lastCost, int level0_ran, float ncc, int iters);
 __device__ __forceinline__ uint32_t lds_off(const void *p);
 
-// 10000 bytes: eight 1280-byte LDS granules, 16 waves per CU (with the accumulators in a member of their own the
+// 9840 bytes: eight 1280-byte LDS granules, 16 waves per CU (with the accumulators in a member of their own the
 // ninth granule cost two resident waves per CU).
+// Bank layout (64 banks x 4 B = a 256-B span; a ds_read_b64 is served in two halves of 32 lanes).  Lane 16 mk + 4 mq + mi
+// reads, as its MFMA operand, stream mi of feature mq at pixel mk + 4 g: byte 64 mi + 16 mq + 8 mk (mod 256) -- per half
+// (mk in {0, 1} or {2, 3}) the streams X / Y / NE occupy [0, 64) [64, 128) [128, 192) resp. [16, 80) [80, 144) [144, 208),
+// the per-feature constants c sit at 192 + 16 mq + 8 mk.  Round 4: `ones` (the A operand of entry 3) used to start at
+// byte 0 of the span, i.e. on the banks of stream X / feature 0 -- every A read was a 2-way conflict, one LDS cycle in
+// three of the chunk phase (SQ_LDS_BANK_CONFLICT 29.8 M of SQ_LDS_IDX_ACTIVE 95.8 M per launch, profiles/r03_f_cfg3).
+// It now starts at byte 160: [160, 176) is free in the first half ([128, 192) holds no A operand), [176, 192) in the
+// second (tools/microbench16.hip: the A pattern reads conflict-free there, the B pattern always did).
 struct QuadLds {
     double chunk[3][4][66];  // X | Y | NE streams of the current chunk: [stream][feature][pixel]; the strides put the
                              // three streams 64 B and the four features 16 B apart modulo the 256-B bank span.
                              // After the last chunk of an iteration its first 64 doubles hold D of the four blocks
                              // (quad_acc) until the solve has read them.
     double cconst[4][34];    // 16 x c per feature (A operand of entry 2, B operand of entry 3), 16 B apart mod 256
-    double ones[32];         // 16 x 1.0 (A operand of entry 3)
-    float sq[4 * 129 + 64];  // per feature: carry, 64 squares; rows 129 floats apart (odd: rows 0/1 use disjoint banks)
+    double pad_[20];         // 160 bytes: puts `ones` on banks no A operand of the same half-wave uses
+    double ones[16];         // 16 x 1.0 (A operand of entry 3: lane mk reads ones[mk + 4 u] for the four groups of a batch)
+    float sq[4 * 129];       // per feature: carry, 64 squares (+ the 32 floats a chain may read past them); rows 129 floats
+                             // apart (odd: the two rows of a 32-lane half use the even / the odd banks); last float read: 387 + 95
 };
+static_assert(offsetof(QuadLds, ones) % 256 == 160 && sizeof(QuadLds) <= 8 * 1280, "QuadLds: bank layout / eight LDS granules");
+__host__ __device__ constexpr int quad_sq_row(int r) { return r * 129; }
 
 __device__ __forceinline__ double (*quad_acc(QuadLds &S))[16] { return reinterpret_cast<double (*)[16]>(&S.chunk[0][0][0]); }
 
@@ -241,8 +254,8 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 
     const QuadOperands ops = quad_operands(S, lane);  // MFMA operand roles of this lane
     const int mk = ops.mk, mq = ops.mq, mi = ops.mi;
-    if (lane < 32) S.ones[lane] = 1.0;
-    const uint32_t sq_addr = lds_off(&S.sq[row * 129]) + 8u * lr;
+    if (lane < 16) S.ones[lane] = 1.0;
+    const uint32_t sq_addr = lds_off(&S.sq[quad_sq_row(row)]) + 8u * lr;
 
     int succ = 1, iters = 0;
     float lastCost = 0.0f;
@@ -384,7 +397,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     S.chunk[0][f][lane] = (double)Ix;
                     S.chunk[1][f][lane] = (double)Iy;
                     S.chunk[2][f][lane] = -(double)e;
-                    S.sq[f * 129 + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
+                    S.sq[quad_sq_row(f) + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
                 };
                 auto first_of = [](unsigned long long m) { return (int)(__builtin_ctzll(m) >> 4); };
                 auto without = [](unsigned long long m, int f) { return m & ~(0xffffull << (16 * f)); };
@@ -422,7 +435,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     asm volatile("; last taps: set b");
                     consume(fb, tb, s1b);
                 }
-                if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
+                if (lr == 0) S.sq[quad_sq_row(row)] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
                 __syncthreads();
                 QSTAMP(1)
                 carry = quad_chunk_phase(ops, P, c, sq_addr, d);  // H, b and cost of the chunk

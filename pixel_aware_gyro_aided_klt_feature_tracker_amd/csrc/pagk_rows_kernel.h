@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
 
     const QuadOperands ops = quad_operands(S, lane);  // MFMA operand roles of this lane
     const int mk = ops.mk, mq = ops.mq, mi = ops.mi;
-    if (lane < 32) S.ones[lane] = 1.0;
-    const uint32_t sq_addr = lds_off(&S.sq[row * 129]) + 8u * lr;
+    if (lane < 16) S.ones[lane] = 1.0;
+    const uint32_t sq_addr = lds_off(&S.sq[quad_sq_row(row)]) + 8u * lr;
     float *ws = a.ws + (size_t)blockIdx.x * (4 * NCH * 64) + lane;  // img1 samples of the rows' current levels
 
     // ---- the row's state: every lane of a row holds the same values -------------------------------------------
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
                 S.chunk[0][f][lane] = (double)Ix;
                 S.chunk[1][f][lane] = (double)Iy;
                 S.chunk[2][f][lane] = -(double)e;
-                S.sq[f * 129 + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
+                S.sq[quad_sq_row(f) + 1 + lane] = valid ? e * e : 0.0f;  // :294; past the patch: + 0.0f changes nothing
             };
             int fa = first_of(actm), fb = 0;
             unsigned long long rest = without(actm, fa);
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64, 4) k_track_rows(TrackArgs a)
                 asm volatile("; last taps: set b");
                 consume(fb, tb);
             }
-            if (lr == 0) S.sq[row * 129] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
+            if (lr == 0) S.sq[quad_sq_row(row)] = carry;  // running cost = first term of this chunk's chain (0 + s == s)
             __syncthreads();
             carry = quad_chunk_phase(ops, P, c, sq_addr, d);  // H, b and cost of the chunk
             __syncthreads();  // the chunk has been read before the next one is written
