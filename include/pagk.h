@@ -173,6 +173,11 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
                             const uint8_t *d_status_in, const pagk_outputs *d_out, int32_t slot_next,
                             const void *d_next, int32_t width, int32_t height, int64_t step, int32_t pyramids);
 int pagk_sync(pagk_ctx *ctx);
+/* For callers that synchronise the stream themselves (pagk_set_stream: a torch stream, the host application's own) and
+ * so never pass through pagk_sync: the error state pagk_sync would have returned, without synchronising.  Call it after
+ * your own synchronisation.  PAGK_E_HIP (once) when a wave of a level-by-level launch (kernel 7) gave up its bounded
+ * wait -- never expected; such a launch also clears its status array, so nothing stale can pass for a tracked point. */
+int pagk_check_launch(pagk_ctx *ctx);
 /* Use an external HIP stream (e.g. torch's current stream) instead of the
  * context's own; pass NULL to restore. */
 int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);

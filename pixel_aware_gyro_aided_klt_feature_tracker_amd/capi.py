@@ -208,6 +208,9 @@ def declare(lib) -> None:
         lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         lib.pagk_selftest_solve.restype = C.c_int
         lib.pagk_selftest_solve.argtypes = [vp, i32, vp, vp, C.c_uint32, vp, vp, vp, vp]
+    if hasattr(lib, "pagk_check_launch"):
+        lib.pagk_check_launch.restype = C.c_int
+        lib.pagk_check_launch.argtypes = [vp]
     if hasattr(lib, "pagk_selftest_repeat_sum"):
         lib.pagk_selftest_repeat_sum.restype = C.c_int
         lib.pagk_selftest_repeat_sum.argtypes = [vp, i32, vp, i32, vp, vp]
@@ -252,7 +255,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
-    "pagk_selftest_repeat_sum",
+    "pagk_selftest_repeat_sum", "pagk_check_launch",
 ]
 
 
@@ -517,6 +520,11 @@ class Context:
 
     def sync(self):
         self._check(self.lib.pagk_sync(self.h), "pagk_sync")
+
+    def check_launch(self):
+        """The error state pagk_sync would return, without synchronising: for callers that synchronise the stream
+        themselves (a torch stream).  Raises PAGK_E_HIP once for a kernel-7 launch in which a wave gave up its wait."""
+        self._check(self.lib.pagk_check_launch(self.h), "pagk_check_launch")
 
     def set_stream(self, stream_ptr: int | None):
         self._check(self.lib.pagk_set_stream(self.h, stream_ptr), "pagk_set_stream")

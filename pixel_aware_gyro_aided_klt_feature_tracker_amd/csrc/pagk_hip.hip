@@ -308,6 +308,20 @@ int lv_check(pagk_ctx *ctx)
     return PAGK_OK;
 }
 
+// Library-owned device buffers that captured graphs point into (quad_ws, lv, susp) may only be reallocated while no
+// instantiated graph of this context is alive: the caller destroys its graphs (pagk_graph_destroy), or runs the larger
+// launch once BEFORE capturing, as include/pagk.h asks.
+int no_live_graphs(pagk_ctx *ctx, const char *what)
+{
+    for (int k = 0; k < pagk_ctx::kGraphs; k++)
+        if (ctx->graph_execs[k]) {
+            snprintf(ctx->err, sizeof(ctx->err), "%s would have to grow while graph %d of this context is alive (its nodes hold the old "
+                     "pointers): destroy the graph first, or run the largest launch once before capturing", what, k);
+            return PAGK_E_ARG;
+        }
+    return PAGK_OK;
+}
+
 int quad_capacity(pagk_ctx *ctx, int half)
 {
     const int slot = half == 5 ? 0 : (half == 7 ? 1 : 2);
@@ -462,6 +476,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     snprintf(ctx->err, sizeof(ctx->err), "the row kernel's workspace would have to be (re)allocated during graph capture");
                     return PAGK_E_ARG;
                 }
+                if (int gr = no_live_graphs(ctx, "the row kernel's workspace")) return gr;
                 if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
                 ctx->quad_ws = nullptr;
                 ctx->quad_ws_bytes = 0;
@@ -495,6 +510,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                     snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
                     return PAGK_E_ARG;
                 }
+                // an instantiated graph keeps the old pointers in its nodes (memset, kernel arguments): replaying it after
+                // the buffers moved would write freed memory
+                if (int gr = no_live_graphs(ctx, "the quad kernel's workspace")) return gr;
                 if (need > ctx->quad_ws_bytes) {
                     if (ctx->quad_ws) HIPCHK(ctx, hipFree(ctx->quad_ws));
                     ctx->quad_ws = nullptr;
@@ -546,6 +564,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                         snprintf(ctx->err, sizeof(ctx->err), "the continuation buffers would have to be (re)allocated during graph capture");
                         return PAGK_E_ARG;
                     }
+                    if (int gr = no_live_graphs(ctx, "the continuation buffers")) return gr;
                     if (ctx->susp) HIPCHK(ctx, hipFree(ctx->susp));
                     ctx->susp = nullptr;
                     ctx->susp_bytes = 0;
@@ -1004,7 +1023,17 @@ int pagk_last_handover(pagk_ctx *ctx)
     int count = 0;
     HIPCHK(ctx, hipMemcpyAsync(&count, ctx->susp_count_dev, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int lr = lv_check(ctx)) return lr;
     return count;
+}
+
+// The error word of the level-by-level launches without a synchronisation: for callers that synchronise the stream
+// themselves (pagk_set_stream, a torch stream) and therefore never pass through pagk_sync.  Call it AFTER that
+// synchronisation.  PAGK_OK, or PAGK_E_HIP once for a launch in which a wave gave up waiting.
+int pagk_check_launch(pagk_ctx *ctx)
+{
+    if (!ctx) return PAGK_E_ARG;
+    return lv_check(ctx);
 }
 
 int pagk_set_concurrency(pagk_ctx *ctx, int32_t streams)
@@ -1420,7 +1449,7 @@ int pagk_graph_destroy(pagk_ctx *ctx, int32_t graph_id)
     (void)hipGraphDestroy(ctx->graphs[graph_id]);
     ctx->graph_execs[graph_id] = nullptr;
     ctx->graphs[graph_id] = nullptr;
-    return PAGK_OK;
+    return lv_check(ctx);
 }
 
 // ---- geometry validation scoring ----------------------------------

@@ -396,10 +396,17 @@ int pagk_track_sharded(pagk_multi *pm, const pagk_params *params, const pagk_ima
     // 3. member 0 hands the gathered slices to the host; everybody drains
     MHIPCHK(pm, hipSetDevice(pm->ctx[0]->device));
     MHIPCHK(pm, hipMemcpyAsync(pm->stage[0].h_all, pm->stage[0].d_all, slice * G, hipMemcpyDeviceToHost, pm->ctx[0]->stream));
+    int lv_rc = PAGK_OK;
     for (int k = 0; k < G; k++) {
         MHIPCHK(pm, hipSetDevice(pm->ctx[k]->device));
         MHIPCHK(pm, hipStreamSynchronize(pm->ctx[k]->stream));
+        // a level-by-level launch whose wait ran out reports here, at the synchronisation that ends it (include/pagk.h)
+        if (int r = lv_check(pm->ctx[k])) {
+            snprintf(pm->err, sizeof pm->err, "rank %d: %s", k, pm->ctx[k]->err);
+            lv_rc = r;
+        }
     }
+    if (lv_rc) return lv_rc;
     const uint8_t *all = static_cast<const uint8_t *>(pm->stage[0].h_all);
     for (int k = 0; k < G; k++) {
         int lo, hi;

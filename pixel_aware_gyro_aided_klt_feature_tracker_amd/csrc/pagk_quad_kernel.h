@@ -64,6 +64,12 @@ __host__ __device__ constexpr int quad_sq_row(int r) { return r * 129; }
 
 __device__ __forceinline__ double (*quad_acc(QuadLds &S))[16] { return reinterpret_cast<double (*)[16]>(&S.chunk[0][0][0]); }
 
+// Comment lines in the ISA that delimit the fence-free hand-offs; __graft_entry__.build() runs tools/isa_handoff.py over the
+// compiler's assembly and refuses a library in which what lies between them has lost its shape (agent scope on every
+// store / load, the s_waitcnt vmcnt(0) in front of the publishing atomic and store).  The clobber keeps the compiler from
+// moving memory operations across a marker.
+#define PAGK_HANDOFF_MARK(text) asm volatile("; pagk-handoff: " text ::: "memory")
+
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // ---- shared by k_track_quad and k_track_rows -----------------------------------------------------------------------
@@ -153,6 +159,11 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
 // CU's vector cache under the waves that are sampling (measured: 4000 features 1.7 ms instead of 0.33), a release per
 // item writes back the XCD's L2 (60000 features 2.8 ms instead of 1.5).  Arithmetic per level and feature is
 // k_track_quad's, so results are bit-identical.
+// The fence-free hand-off below is an argument about gfx942 / gfx950 (in-order return of a wave's loads, what vmcnt
+// counts for an sc1 store); it is not the HIP memory model's.  Another target must not build it silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "k_track_quad<.., LEVELS>: the level-to-level hand-off is written for gfx942 / gfx950 (see DESIGN.md section 4.3 (f))"
+#endif
 template <int NCH, bool LEAN = false, bool LEVELS = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
@@ -186,21 +197,31 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             int polls = 0, e;
             while ((e = ld_agent(entry)) == 0) {
                 if (++polls > a.lv_polls) {
+                    // (never expected.)  The host reports the launch as failed at its next synchronisation; and because a
+                    // caller on its own stream may never pass through one of ours, nothing stale may pass for a result:
+                    // the quads this wave -- and, for want of its hand-off, the waves below it -- will not track are
+                    // unknown here, so the launch's status array is cleared by the first wave that gives up
                     if (lane == 0) st_agent(a.lv_error, 1);
-                    return;  // (results are void: the host reports the launch as failed)
+                    for (int k = lane; k < a.n; k += 64) a.status[k] = 0;
+                    return;
                 }
                 __builtin_amdgcn_s_sleep(127);
             }
+            // (what is loaded below from lv_state is indexed by `quad`, i.e. by the VALUE just loaded: the state loads are
+            // address-dependent on the entry and a wave's loads return in order -- that dependency is the consumer's
+            // ordering; do not index the state by the ticket)
             quad = __builtin_amdgcn_readfirstlane(e) - 1;
         }
     }
     // LEVELS: this wave's quad is through with its level -- the next level's consumers may have it
     auto lv_publish = [&]() {
+        PAGK_HANDOFF_MARK("publish begin");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows' state has reached the coherence point
         if (lane == 0) {
             const int slot = atomicAdd(a.queue + kLvSeqStride * lv_seq + 64 * (1 + lv_step), 1);
             st_agent(a.lv_ready + ((size_t)lv_step * 8 + lv_seq) * lv_cmax + slot, quad + 1);
         }
+        PAGK_HANDOFF_MARK("publish end");
     };
     // hand-over: this wave hands nothing over from here on (the finishers stop waiting once every wave has said so; its
     // list entries were stored with agent-scope atomics behind a fence of their own, this wave's instruction order does
@@ -262,10 +283,12 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     bool susp = false;  // this row's feature was handed to k_track_resume (TrackArgs::iter_budget)
     if constexpr (LEVELS) {
         if (lv_step > 0) {  // take over from the item of the level above
+            PAGK_HANDOFF_MARK("take-over begin");
             const int *st = reinterpret_cast<const int *>(a.lv_state + 4 * (size_t)fi);
             p2x = __int_as_float(ld_agent(st + 0)), p2y = __int_as_float(ld_agent(st + 1));
             iters = ld_agent(st + 2);
             susp = ld_agent(st + 3) != 0;  // handed to the latency kernel on a level above
+            PAGK_HANDOFF_MARK("take-over end");
         }
     }
     const int level_first = LEVELS ? a.n_levels - 1 - lv_step : a.n_levels - 1;
@@ -495,11 +518,13 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 #undef QSTAMP
     if constexpr (LEVELS) {
         if (level_last > 0) {  // hand the quad to the next level: state, then the ready-list entry that publishes it
+            PAGK_HANDOFF_MARK("state begin");
             if (lr == 0 && raw < a.n) {
                 int *st = reinterpret_cast<int *>(a.lv_state + 4 * (size_t)fi);
                 st_agent(st + 0, __float_as_int(p2x)), st_agent(st + 1, __float_as_int(p2y)), st_agent(st + 2, iters);
                 st_agent(st + 3, susp ? 1 : 0);
             }
+            PAGK_HANDOFF_MARK("state end");
             lv_publish();
             wave_ended();
             return;

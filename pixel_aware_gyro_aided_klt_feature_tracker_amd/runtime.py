@@ -371,6 +371,9 @@ class ResidentTracker:
             self.cur_slot = 3 - self.cur_slot
 
     def synchronize(self):
-        """Wait for everything step() has issued (tracking on `main`, prefetch / gather on `side`)."""
+        """Wait for everything step() has issued (tracking on `main`, prefetch / gather on `side`); then ask the library
+        whether one of those launches failed -- these are torch's stream synchronisations, not pagk_sync, so the error
+        word of the level-by-level launches (include/pagk.h: pagk_check_launch) would otherwise never be read."""
         self.main.synchronize()
         self.side.synchronize()
+        self.ctx.check_launch()

@@ -131,6 +131,63 @@ def test_frame_based_constructor_drives_patchmatch_on_the_gpu(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_every_public_patchmatch_method_on_the_gpu(built, tmp_path):
+    """tests/patch_match_methods_gpu_test.cpp: the seven public methods of the reference's PatchMatch
+    (include/patch_match.h:51-69) through the API shell -- CreatePyramids, ..._onePixel level by level, DistortPoints and
+    SetMatcher must leave the tracker's six result vectors bit-identical to OpticalFlowMultiLevel(); GetPixelValue and NCC
+    are the host-side members (the NCC column of the comparison is device vs host)."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = capi.PKG_DIR
+    exe = str(tmp_path / "patch_match_methods_gpu_test")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), os.path.join(root, "tests", "patch_match_methods_gpu_test.cpp"),
+                    "-o", exe, "-L", pkg, "-l:libpagk_tracker.so", "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    cam, w, _, K32 = _scene(n=96)
+    n = w.n
+    wv = -np.array((0.3, -0.4, 1.2)) + np.array((0.06, -0.04, 0.08))
+    fin = str(tmp_path / "in.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", 320, 240, n))
+        f.write(w.img_ref.tobytes()); f.write(w.img_cur.tobytes()); f.write(w.pt_ref.astype(np.float32).tobytes())
+        f.write(struct.pack("<4f", cam.fx, cam.fy, cam.cx, cam.cy)); f.write(np.asarray(cam.dist[:4], np.float32).tobytes())
+        f.write(struct.pack("<3f", *wv)); f.write(struct.pack("<f", 0.05))
+    r = subprocess.run([exe, fin], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "every public PatchMatch method ok" in r.stdout
+
+
+def test_the_shell_declares_every_public_method_of_the_reference_class(built, tmp_path):
+    """Compile-only (no GPU): a translation unit that takes the address of each public member the reference's
+    include/patch_match.h:44-69 declares, with the reference's signatures."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = capi.PKG_DIR
+    src = tmp_path / "surface.cpp"
+    src.write_text("""
+#include "gyro_aided_tracker.h"
+#include "patch_match.h"
+void (PatchMatch::*a)() = &PatchMatch::CreatePyramids;
+void (PatchMatch::*b)() = &PatchMatch::OpticalFlowMultiLevel;
+void (PatchMatch::*c)(const int, const bool, const bool, const bool) = &PatchMatch::OpticalFlowConsideringIlluminationChange_onePixel;
+void (PatchMatch::*d)() = &PatchMatch::SetMatcher;
+float (PatchMatch::*e)(const cv::Mat &, float, float) const = &PatchMatch::GetPixelValue;
+void (PatchMatch::*f)() = &PatchMatch::DistortPoints;
+float (PatchMatch::*g)(int, const cv::Mat &, const cv::Mat &, const cv::Point2f &, const cv::Point2f &, const cv::Mat &) = &PatchMatch::NCC;
+PatchMatch *make(GyroAidedTracker *t) { return new PatchMatch(t, 5, 10, 3, true, false, true, true); }
+int main() { return a && b && c && d && e && f && g ? 0 : 1; }
+""")
+    exe = str(tmp_path / "surface")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(pkg, "csrc", "host"),
+                    str(src), "-o", exe, "-L", pkg, "-l:libpagk_tracker.so", "-l:libpagk_hip.so", f"-Wl,-rpath,{pkg}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("type_", [2, 3, 4, 5, 6])
 def test_shell_track_features_end_to_end(built, type_):
     # the whole reference call stack for one frame pair, every eType, against the oracle chain
