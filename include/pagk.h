@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 300 /* 0.3.0: pipelined 4-wave kernel, pagk_selftest_repeat_sum */
+#define PAGK_VERSION 301 /* 0.3.1: pipelined 4-wave kernel, pagk_track_device_batch, pagk_check_launch, pagk_selftest_repeat_sum */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -172,6 +172,21 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
                             const float *d_pt_ref_un, const float *d_pt_init_un, const float *d_affine,
                             const uint8_t *d_status_in, const pagk_outputs *d_out, int32_t slot_next,
                             const void *d_next, int32_t width, int32_t height, int64_t step, int32_t pyramids);
+/* pagk_track_device for k camera streams that share one device, as ONE launch (BASELINE configs[4]: "batched
+ * multi-camera").  The reference builds one PatchMatch per tracker (src/gyro_aided_tracker.cpp:276-283); this is k of those
+ * calls at once: stream j is context ctxs[j] (its frame slots slot_ref[j] / slot_cur[j] hold the pyramids), n[j] features
+ * in the device arrays d_pt_ref_un[j], d_pt_init_un[j], d_affine[j], d_status_in[j], results to d_out[j]; `params` is
+ * common to all (the trackers of one application are configured alike).  Results per stream are bit-identical to its own
+ * pagk_track_device.  From 6000 features in total (or pagk_set_kernel(ctxs[0], 7)) the streams are served by one launch
+ * of variant 7 whose four-feature groups carry their stream; smaller batches, calculate_ncc and one-level pyramids run
+ * as k launches.  The launch is issued on ctxs[0]'s stream: it waits for what the other contexts' streams have enqueued
+ * so far, and their later work waits for it (contexts switched to one common stream with pagk_set_stream need neither,
+ * and can be captured together: pagk_graph_begin(ctxs[0]) ... pagk_graph_end).  Pointer arrays are host arrays of device
+ * pointers; d_pt_init_un / d_affine may be NULL when the flags do not use them.  k <= 64, all contexts on one device. */
+int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params *params, const int32_t *slot_ref,
+                            const int32_t *slot_cur, const int32_t *n, const float *const *d_pt_ref_un,
+                            const float *const *d_pt_init_un, const float *const *d_affine,
+                            const uint8_t *const *d_status_in, const pagk_outputs *d_out);
 int pagk_sync(pagk_ctx *ctx);
 /* For callers that synchronise the stream themselves (pagk_set_stream: a torch stream, the host application's own) and
  * so never pass through pagk_sync: the error state pagk_sync would have returned, without synchronising.  Call it after

@@ -154,6 +154,9 @@ def declare(lib) -> None:
     lib.pagk_frame_download_level.argtypes = [vp, i32, i32, vp, _P(i32), _P(i32)]
     lib.pagk_track_device.restype = C.c_int
     lib.pagk_track_device.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs)]
+    if hasattr(lib, "pagk_track_device_batch"):
+        lib.pagk_track_device_batch.restype = C.c_int
+        lib.pagk_track_device_batch.argtypes = [vp, i32, _P(Params), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.pagk_track_device_fused.restype = C.c_int
     lib.pagk_track_device_fused.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs), i32, vp, i32, i32,
                                             C.c_int64, i32]
@@ -255,7 +258,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
-    "pagk_selftest_repeat_sum", "pagk_check_launch",
+    "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch",
 ]
 
 
@@ -360,6 +363,23 @@ class Context:
         self._check(self.lib.pagk_track_device(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
                                                _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o)),
                     "pagk_track_device")
+
+    @staticmethod
+    def track_device_batch(ctxs, params: Params, slots_ref, slots_cur, ns, d_pt_ref, d_pt_init, d_affine, d_status, d_outs):
+        """pagk_track_device_batch: k camera streams (contexts `ctxs`, all on one device) as ONE launch, issued on
+        ctxs[0]'s stream.  Per stream j: frame slots, feature count and device arrays (torch tensors / addresses) as for
+        track_device; d_pt_init / d_affine may be None."""
+        k = len(ctxs)
+        lib = ctxs[0].lib
+        hs = (C.c_void_p * k)(*[c.h for c in ctxs])
+        sr, sc, nn = (C.c_int32 * k)(*slots_ref), (C.c_int32 * k)(*slots_cur), (C.c_int32 * k)(*ns)
+
+        def ptrs(lst):
+            return None if lst is None else (C.c_void_p * k)(*[_ptr(t) for t in lst])
+        outs = (Outputs * k)(*[outputs_struct(o) for o in d_outs])
+        rc = lib.pagk_track_device_batch(hs, k, C.byref(params), sr, sc, nn, ptrs(d_pt_ref), ptrs(d_pt_init), ptrs(d_affine),
+                                         ptrs(d_status), outs)
+        ctxs[0]._check(rc, "pagk_track_device_batch")
 
     def track_device_fused(self, params: Params, slot_ref: int, slot_cur: int, n: int, d_pt_ref, d_pt_init, d_affine,
                            d_status, d_out: dict, slot_next: int, d_next_ptr: int, width: int, height: int, step: int,

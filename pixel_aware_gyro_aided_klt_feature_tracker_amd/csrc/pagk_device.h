@@ -42,6 +42,23 @@ struct SuspState {
     int iters;     // iterations executed so far, all levels (diagnostic output)
 };
 
+// One camera stream of a batched launch (pagk_track_device_batch: k_track_quad<.., LEVELS, BATCH>): what differs from
+// stream to stream -- both pyramids, the per-feature arrays and their count.  Everything else (patch size, iteration
+// limit, flags, camera model) is the launch's.  Quads are numbered through the batch: stream s owns the quads
+// [quad_base, quad_base + ceil(n / 4)).
+struct BatchStream {
+    DevLevel l1[kMaxLevels], l2[kMaxLevels];
+    const float *pt_ref, *pt_init, *affine;
+    const uint8_t *status_in;
+    float *pt_un, *pt_dist;
+    uint8_t *status;
+    double *pix_err, *dist_pred;
+    float *ncc;
+    int *iters;
+    int n;
+    int quad_base;
+};
+
 struct TrackArgs {
     DevLevel l1[kMaxLevels], l2[kMaxLevels];
     float scales[kMaxLevels];
@@ -81,6 +98,8 @@ struct TrackArgs {
     int *lv_error;
     int lv_shift;      // test knob: a wave starts with the sequence of XCD (its own + lv_shift) mod 8 -- every hand-off then crosses XCDs
     int lv_polls;      // looks (~3 us apart) a wave takes at its ready-list entry before it gives up (bounded: never a hang)
+    const BatchStream *batch;  // batched launch: batch_k streams (device memory); n is then 4 x the batch's quads
+    int batch_k;
     int half, iterations;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)

@@ -58,6 +58,9 @@ struct pagk_ctx {
     int *susp_count_dev = nullptr;  // the hand-over count of the last launch that used one (in `susp` or in `lv`)
     void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (8 x 4096 B) | ready lists | float state[4 n]
     size_t lv_bytes = 0;
+    void *batch_dev = nullptr, *batch_host = nullptr;  // pagk_track_device_batch (lead context): the BatchStream array and its pinned mirror
+    int batch_cap = 0;
+    hipEvent_t ev_batch = nullptr;  // orders a batched launch against the streams of the contexts it serves
     int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
     int *lv_error_dev = nullptr;  // ... as the device addresses it
     hipStream_t aux_stream = nullptr;  // the live finisher's stream
@@ -136,6 +139,16 @@ int level_dims(int w, int h, int L, int *lw, int *lh)
     return PAGK_OK;
 }
 
+// Is this context's work being recorded rather than executed?  Its own capture (pagk_graph_begin), or a capture of
+// the stream it was switched to by somebody else -- another context of a batch (pagk_track_device_batch), the host
+// application's own hipStreamBeginCapture.  Nothing may allocate then, and timing events are left out.
+bool in_capture(pagk_ctx *ctx)
+{
+    if (ctx->capturing) return true;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+}
+
 int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
 {
     int lw[kMaxLevels], lh[kMaxLevels];
@@ -151,7 +164,7 @@ int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
         total = align_up(total + (size_t)lw[l] * lh[l] * 4, 256);
     }
     if (total > s.block_bytes) {
-        if (ctx->capturing) {  // run the same calls once before pagk_graph_begin so that nothing allocates here
+        if (in_capture(ctx)) {  // run the same calls once before pagk_graph_begin so that nothing allocates here
             snprintf(ctx->err, sizeof(ctx->err), "frame slot would have to be (re)allocated during graph capture");
             return PAGK_E_ARG;
         }
@@ -217,7 +230,7 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
     int lw[kMaxLevels], lh[kMaxLevels];
     level_dims(s.w, s.h, s.L, lw, lh);
     dim3 blk(32, 8);
-    if (ctx->ev_pyr[0] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
+    if (ctx->ev_pyr[0] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[0], ctx->stream));
     // the fused kernel re-derives every level from level 0 by nested 2x2 means: valid while every parent is
     // even in both dimensions (the exact-2x case of cv::resize); otherwise level by level
     bool all_even = true;
@@ -227,8 +240,8 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
         const int nb = make_pyr_args(s, src0, pitch0, wrap0, &pa);
         hipLaunchKernelGGL(k_pyramid_fused, dim3(nb), dim3(256), 0, ctx->stream, pa);
         HIPCHK(ctx, hipGetLastError());
-        if (ctx->ev_pyr[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
-        if (!ctx->capturing) ctx->pyr_timed = true;
+        if (ctx->ev_pyr[1] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+        if (!in_capture(ctx)) ctx->pyr_timed = true;
         s.wrap0 = wrap0;
         s.valid = true;
         return PAGK_OK;
@@ -251,8 +264,8 @@ int slot_build(pagk_ctx *ctx, FrameSlot &s, const uint8_t *src0, int64_t pitch0,
                            s.quad[l]);
     }
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->ev_pyr[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
-    if (!ctx->capturing) ctx->pyr_timed = true;
+    if (ctx->ev_pyr[1] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_pyr[1], ctx->stream));
+    if (!in_capture(ctx)) ctx->pyr_timed = true;
     s.wrap0 = wrap0;
     s.valid = true;
     return PAGK_OK;
@@ -348,10 +361,8 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
     const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
     // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
     // finisher that starts after the throughput kernel is the plain sweep: +13 %)
-    if (ctx->concurrency != 1 || !exposed_tail || ctx->capturing) return 0;
-    // the caller's own capture of the stream (not through pagk_graph_begin) counts as well
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    // (the caller's own capture of the stream, not through pagk_graph_begin, counts as well: in_capture)
+    if (ctx->concurrency != 1 || !exposed_tail || in_capture(ctx)) return 0;
     return 20;
 }
 
@@ -368,15 +379,40 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
 // profiles/r03_levels_sweep_only.log): in a capture, up to 1.25 rounds.
 int levels_budget_for(pagk_ctx *ctx, int quads, int iterations, int levels, int half, bool *live)
 {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    const bool in_capture = ctx->capturing || hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
-    *live = !in_capture || ctx->quad_budget >= 0;   // (a forced budget keeps the parallel branch: tests)
+    const bool captured = in_capture(ctx);
+    *live = !captured || ctx->quad_budget >= 0;   // (a forced budget keeps the parallel branch: tests)
     if (ctx->quad_budget >= 0) return ctx->quad_budget;
     if (iterations * levels < 60 || ctx->concurrency != 1) return 0;
     const long long cap = quad_capacity(ctx, half);
     if (100ll * quads <= 45 * cap) return 0;
-    if (in_capture && 100ll * quads > 125 * cap) return 0;
+    if (captured && 100ll * quads > 125 * cap) return 0;
     return 20;
+}
+
+// What a launch takes from pagk_params: the constructor's constants (src/patch_match.cpp:48-57) and the camera model.
+void fill_param_args(TrackArgs &a, const pagk_params *p)
+{
+    a.half = p->half_patch;
+    a.iterations = p->iterations;
+    a.has_gyro = p->has_gyro_predict_initial;
+    a.illum = p->consider_illumination;
+    a.use_affine = p->consider_affine;
+    a.penalty = p->regularization_penalty;
+    a.calc_ncc = p->calculate_ncc;
+    a.solver = p->solver_variant;
+    float invlog = p->inv_log_max_dist != 0.0f ? p->inv_log_max_dist
+                                               : pagk_inv_log_max_dist(p->alpha, p->max_distance);
+    a.lam_invlog = p->lambda * invlog;           // :305  mLambda * mInvLogMaxDist (float)
+    a.lam_invlog_alpha = a.lam_invlog * p->alpha; // :307  ... * mAlpha (float)
+    a.alpha = p->alpha;
+    // :57  1.0f / (2.0f*h + 1.0f) / (2.0f*h + 1.0f), float, stored in a double
+    a.win_size_inv = (double)(1.0f / (2.0f * p->half_patch + 1.0f) / (2.0f * p->half_patch + 1.0f));
+    a.distort_on = p->dist_coef[0] != 0.0f;  // :410
+    a.fx = p->fx, a.fy = p->fy, a.cx = p->cx, a.cy = p->cy;
+    a.fx_inv = (float)(1.0 / (double)p->fx);  // src/utils.cpp:53
+    a.fy_inv = (float)(1.0 / (double)p->fy);
+    a.k1 = p->dist_coef[0], a.k2 = p->dist_coef[1], a.p1 = p->dist_coef[2], a.p2 = p->dist_coef[3];
+    a.k3 = p->n_dist_coef == 5 ? p->dist_coef[4] : 0.0f;
 }
 
 int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const FrameSlot &sc, int n,
@@ -408,29 +444,9 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
 #if defined(PAGK_STAMPS) || defined(PAGK_COUNT_REDO) || defined(PAGK_TIC)
     a.dbg = reinterpret_cast<unsigned long long *>(getenv("PAGK_DBG_PTR") ? strtoull(getenv("PAGK_DBG_PTR"), nullptr, 0) : 0ull);
 #endif
-    a.half = p->half_patch;
-    a.iterations = p->iterations;
-    a.has_gyro = p->has_gyro_predict_initial;
-    a.illum = p->consider_illumination;
-    a.use_affine = p->consider_affine;
-    a.penalty = p->regularization_penalty;
-    a.calc_ncc = p->calculate_ncc;
-    a.solver = p->solver_variant;
-    float invlog = p->inv_log_max_dist != 0.0f ? p->inv_log_max_dist
-                                               : pagk_inv_log_max_dist(p->alpha, p->max_distance);
-    a.lam_invlog = p->lambda * invlog;           // :305  mLambda * mInvLogMaxDist (float)
-    a.lam_invlog_alpha = a.lam_invlog * p->alpha; // :307  ... * mAlpha (float)
-    a.alpha = p->alpha;
-    // :57  1.0f / (2.0f*h + 1.0f) / (2.0f*h + 1.0f), float, stored in a double
-    a.win_size_inv = (double)(1.0f / (2.0f * p->half_patch + 1.0f) / (2.0f * p->half_patch + 1.0f));
-    a.distort_on = p->dist_coef[0] != 0.0f;  // :410
-    a.fx = p->fx, a.fy = p->fy, a.cx = p->cx, a.cy = p->cy;
-    a.fx_inv = (float)(1.0 / (double)p->fx);  // src/utils.cpp:53
-    a.fy_inv = (float)(1.0 / (double)p->fy);
-    a.k1 = p->dist_coef[0], a.k2 = p->dist_coef[1], a.p1 = p->dist_coef[2], a.p2 = p->dist_coef[3];
-    a.k3 = p->n_dist_coef == 5 ? p->dist_coef[4] : 0.0f;
+    fill_param_args(a, p);
 
-    if (ctx->ev_trk[0] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
+    if (ctx->ev_trk[0] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
     if (n > 0) {
         const int Pm = (2 * a.half + 1) * (2 * a.half + 1);
         // MFMA variant: instantiated for the common patch sizes; chosen explicitly (kernel 2) or,
@@ -472,7 +488,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             if (ctx->rows_waves_cap > 0 && waves > ctx->rows_waves_cap) waves = ctx->rows_waves_cap;
             const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
             if (need > ctx->quad_ws_bytes) {
-                if (ctx->capturing) {
+                if (in_capture(ctx)) {
                     snprintf(ctx->err, sizeof(ctx->err), "the row kernel's workspace would have to be (re)allocated during graph capture");
                     return PAGK_E_ARG;
                 }
@@ -506,7 +522,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             const size_t susp_zero = 256 + align_up((size_t)n * 4, 256);
             const size_t need_lv = use_levels ? 32768 + ready_bytes + susp_zero + (size_t)n * 16 + (size_t)n * sizeof(SuspState) : 0;
             if (need > ctx->quad_ws_bytes || need_lv > ctx->lv_bytes) {
-                if (ctx->capturing) {
+                if (in_capture(ctx)) {
                     snprintf(ctx->err, sizeof(ctx->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
                     return PAGK_E_ARG;
                 }
@@ -560,7 +576,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             } else if (handover) {
                 const size_t need_s = 256 + align_up((size_t)n * 4, 256) + (size_t)n * sizeof(SuspState);
                 if (need_s > ctx->susp_bytes) {
-                    if (ctx->capturing) {
+                    if (in_capture(ctx)) {
                         snprintf(ctx->err, sizeof(ctx->err), "the continuation buffers would have to be (re)allocated during graph capture");
                         return PAGK_E_ARG;
                     }
@@ -720,8 +736,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         }
         HIPCHK(ctx, hipGetLastError());
     }
-    if (ctx->ev_trk[1] && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[1], ctx->stream));
-    if (!ctx->capturing) ctx->trk_timed = true;
+    if (ctx->ev_trk[1] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[1], ctx->stream));
+    if (!in_capture(ctx)) ctx->trk_timed = true;
     return PAGK_OK;
 }
 
@@ -951,7 +967,8 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_LEVEL_POLLS")) ctx->level_polls = atoi(getenv("PAGK_LEVEL_POLLS"));
     if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess) {
         pagk_destroy(ctx);
         return PAGK_E_HIP;
     }
@@ -990,6 +1007,9 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->susp) (void)hipFree(ctx->susp);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->lv) (void)hipFree(ctx->lv);
+    if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+    if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
+    if (ctx->ev_batch) (void)hipEventDestroy(ctx->ev_batch);
     if (ctx->lv_error) (void)hipHostFree(ctx->lv_error);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_trk[k]) (void)hipEventDestroy(ctx->ev_trk[k]);
@@ -1162,6 +1182,169 @@ int pagk_track_device(pagk_ctx *ctx, const pagk_params *params, int32_t slot_ref
     if (n > 0 && params->consider_affine && !d_affine) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return launch_track(ctx, params, sr, sc, n, d_pt_ref_un, d_pt_init_un, d_affine, d_status_in, d_out);
+}
+
+// One launch for k camera streams that share this device (BASELINE configs[4], "batched multi-camera").  The reference
+// builds one PatchMatch per tracker (src/gyro_aided_tracker.cpp:276-283); k trackers' calls are k independent feature
+// sets over k image pairs.  As k launches they are k launches of a few thousand features -- the latency variants' size,
+// or the throughput variant run as k concurrent grids that hold each other's slots; as ONE launch of variant 7 (four
+// features per wave, one pyramid level per wave; a quad carries its stream) they are a launch of several rounds of
+// resident waves, which is where that variant is at its rate.  Per stream: the bits of its own pagk_track_device.
+int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params *params, const int32_t *slot_ref,
+                            const int32_t *slot_cur, const int32_t *n, const float *const *d_pt_ref_un,
+                            const float *const *d_pt_init_un, const float *const *d_affine,
+                            const uint8_t *const *d_status_in, const pagk_outputs *d_out)
+{
+    if (!ctxs || k < 1 || k > 64 || !slot_ref || !slot_cur || !n || !d_pt_ref_un || !d_status_in || !d_out) return PAGK_E_ARG;
+    for (int j = 0; j < k; j++)
+        if (!ctxs[j]) return PAGK_E_ARG;
+    pagk_ctx *lead = ctxs[0];
+    int rc = check_params(params);
+    if (rc) return rc;
+    long long total_n = 0;
+    int total_q = 0;
+    for (int j = 0; j < k; j++) {
+        pagk_ctx *c = ctxs[j];
+        if (c->device != lead->device) {
+            snprintf(lead->err, sizeof(lead->err), "pagk_track_device_batch: context %d lives on device %d, the first on %d", j, c->device, lead->device);
+            return PAGK_E_ARG;
+        }
+        if (slot_ref[j] < 0 || slot_ref[j] >= kUserSlots || slot_cur[j] < 0 || slot_cur[j] >= kUserSlots) return PAGK_E_ARG;
+        const FrameSlot &sr = c->slots[slot_ref[j]], &sc = c->slots[slot_cur[j]];
+        if (!sr.valid || !sc.valid || sr.L < params->pyramids || sc.L < params->pyramids || sr.w != sc.w || sr.h != sc.h) return PAGK_E_ARG;
+        if (n[j] < 0 || !d_out[j].pt_un || !d_out[j].status) return PAGK_E_ARG;
+        if (n[j] > 0 && (!d_pt_ref_un[j] || !d_status_in[j])) return PAGK_E_ARG;
+        if (n[j] > 0 && params->has_gyro_predict_initial && (!d_pt_init_un || !d_pt_init_un[j])) return PAGK_E_ARG;
+        if (n[j] > 0 && params->consider_affine && (!d_affine || !d_affine[j])) return PAGK_E_ARG;
+        total_n += n[j];
+        total_q += (n[j] + 3) / 4;
+    }
+    HIPCHK(lead, hipSetDevice(lead->device));
+    const bool mfma_ok = params->half_patch == 5 || params->half_patch == 7 || params->half_patch == 10;
+    const bool batched = mfma_ok && !params->calculate_ncc && params->pyramids >= 2 && lead->lv_error && total_q > 0 &&
+                         (lead->kernel == 7 || (lead->kernel == 0 && total_n >= lead->levels_min_features));
+    if (!batched) {
+        // every stream as its own launch on its own context (small batches, NCC launches, a forced variant)
+        for (int j = 0; j < k; j++) {
+            pagk_ctx *c = ctxs[j];
+            rc = launch_track(c, params, c->slots[slot_ref[j]], c->slots[slot_cur[j]], n[j], d_pt_ref_un[j],
+                              d_pt_init_un ? d_pt_init_un[j] : nullptr, d_affine ? d_affine[j] : nullptr, d_status_in[j], &d_out[j]);
+            if (rc) {
+                if (c != lead) snprintf(lead->err, sizeof(lead->err), "stream %d: %s", j, c->err);
+                return rc;
+            }
+        }
+        return PAGK_OK;
+    }
+    TrackArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_levels = params->pyramids;
+    for (int l = 0; l < params->pyramids; l++) a.scales[l] = l == 0 ? 1.0f : (float)((double)a.scales[l - 1] * 0.5);  // :66,:73
+    fill_param_args(a, params);
+    a.n = 4 * total_q;   // features numbered through the batch, each stream padded to whole quads
+    a.batch_k = k;
+    // the stream descriptors: pinned mirror -> device (inside a capture the copy is a node of the graph)
+    if (k > lead->batch_cap) {
+        if (in_capture(lead)) {
+            snprintf(lead->err, sizeof(lead->err), "the batch descriptors would have to be (re)allocated during graph capture");
+            return PAGK_E_ARG;
+        }
+        if (int gr = no_live_graphs(lead, "the batch descriptors")) return gr;
+        if (lead->batch_dev) HIPCHK(lead, hipFree(lead->batch_dev));
+        if (lead->batch_host) HIPCHK(lead, hipHostFree(lead->batch_host));
+        lead->batch_dev = lead->batch_host = nullptr, lead->batch_cap = 0;
+        HIPCHK(lead, hipMalloc(&lead->batch_dev, (size_t)k * sizeof(BatchStream)));
+        HIPCHK(lead, hipHostMalloc(&lead->batch_host, (size_t)k * sizeof(BatchStream), hipHostMallocDefault));
+        lead->batch_cap = k;
+    }
+    BatchStream *hb = static_cast<BatchStream *>(lead->batch_host);
+    int qb = 0;
+    for (int j = 0; j < k; j++) {
+        pagk_ctx *c = ctxs[j];
+        BatchStream &B = hb[j];
+        memset(&B, 0, sizeof B);
+        for (int l = 0; l < params->pyramids; l++) {
+            fill_level(B.l1[l], c->slots[slot_ref[j]], l);
+            fill_level(B.l2[l], c->slots[slot_cur[j]], l);
+        }
+        B.pt_ref = d_pt_ref_un[j];
+        B.pt_init = d_pt_init_un ? d_pt_init_un[j] : nullptr;
+        B.affine = d_affine ? d_affine[j] : nullptr;
+        B.status_in = d_status_in[j];
+        B.pt_un = d_out[j].pt_un, B.pt_dist = d_out[j].pt_dist, B.status = d_out[j].status;
+        B.pix_err = d_out[j].pix_err, B.dist_pred = d_out[j].dist_pred, B.ncc = d_out[j].ncc, B.iters = d_out[j].iters;
+        B.n = n[j];
+        B.quad_base = qb;
+        qb += (n[j] + 3) / 4;
+    }
+    // the launch reads what the other contexts' streams produced (their pyramids, their prediction kernels' outputs) ...
+    for (int j = 1; j < k; j++)
+        if (ctxs[j]->stream != lead->stream) {
+            HIPCHK(lead, hipEventRecord(ctxs[j]->ev_batch, ctxs[j]->stream));
+            HIPCHK(lead, hipStreamWaitEvent(lead->stream, ctxs[j]->ev_batch, 0));
+        }
+    HIPCHK(lead, hipMemcpyAsync(lead->batch_dev, hb, (size_t)k * sizeof(BatchStream), hipMemcpyHostToDevice, lead->stream));
+    a.batch = static_cast<const BatchStream *>(lead->batch_dev);
+    // workspaces of a one-level-per-wave launch (launch_track), for the batch's quads; no hand-over
+    const int Pm = (2 * a.half + 1) * (2 * a.half + 1), nch = (Pm + 63) / 64, nq = total_q, waves = nq * params->pyramids;
+    const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
+    const size_t ready_bytes = align_up((size_t)(params->pyramids - 1) * 8 * ((nq + 7) / 8) * 4, 256);
+    const size_t susp_zero = 256 + align_up((size_t)a.n * 4, 256);
+    const size_t need_lv = 32768 + ready_bytes + susp_zero + (size_t)a.n * 16 + (size_t)a.n * sizeof(SuspState);
+    if (need > lead->quad_ws_bytes || need_lv > lead->lv_bytes) {
+        if (in_capture(lead)) {
+            snprintf(lead->err, sizeof(lead->err), "the quad kernel's workspace would have to be (re)allocated during graph capture");
+            return PAGK_E_ARG;
+        }
+        if (int gr = no_live_graphs(lead, "the quad kernel's workspace")) return gr;
+        if (need > lead->quad_ws_bytes) {
+            if (lead->quad_ws) HIPCHK(lead, hipFree(lead->quad_ws));
+            lead->quad_ws = nullptr, lead->quad_ws_bytes = 0;
+            HIPCHK(lead, hipMalloc(&lead->quad_ws, need));
+            lead->quad_ws_bytes = need;
+        }
+        if (need_lv > lead->lv_bytes) {
+            if (lead->lv) HIPCHK(lead, hipFree(lead->lv));
+            lead->lv = nullptr, lead->lv_bytes = 0;
+            HIPCHK(lead, hipMalloc(&lead->lv, need_lv));
+            lead->lv_bytes = need_lv;
+        }
+    }
+    uint8_t *lb = static_cast<uint8_t *>(lead->lv);
+    a.ws = static_cast<float *>(lead->quad_ws);
+    a.queue = reinterpret_cast<int *>(lb);
+    a.lv_ready = reinterpret_cast<int *>(lb + 32768);
+    a.lv_state = reinterpret_cast<float *>(lb + 32768 + ready_bytes + susp_zero);
+    a.lv_error = lead->lv_error_dev;
+    a.lv_polls = lead->level_polls;
+    a.lv_shift = lead->levels_shift;
+    HIPCHK(lead, hipMemsetAsync(lb, 0, 32768 + ready_bytes, lead->stream));
+    if (lead->ev_trk[0] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_trk[0], lead->stream));
+    const bool lean = !a.penalty && a.solver == 0;
+    auto launch = [&](auto kern) -> hipError_t {
+        hipLaunchKernelGGL(kern, dim3(waves), dim3(64), 0, lead->stream, a);
+        return hipGetLastError();
+    };
+    hipError_t e = hipErrorInvalidValue;
+    if (a.half == 5) e = lean ? launch(k_track_quad<2, true, true, true>) : launch(k_track_quad<2, false, true, true>);
+    else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true, true>) : launch(k_track_quad<4, false, true, true>);
+    else e = lean ? launch(k_track_quad<7, true, true, true>) : launch(k_track_quad<7, false, true, true>);
+    HIPCHK(lead, e);
+    if (lead->ev_trk[1] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_trk[1], lead->stream));
+    if (!in_capture(lead)) lead->trk_timed = true;
+    // ... and whatever those streams do next sees its results
+    bool others = false;
+    for (int j = 1; j < k; j++) others = others || ctxs[j]->stream != lead->stream;
+    if (others) {
+        HIPCHK(lead, hipEventRecord(lead->ev_batch, lead->stream));
+        for (int j = 1; j < k; j++)
+            if (ctxs[j]->stream != lead->stream) HIPCHK(lead, hipStreamWaitEvent(ctxs[j]->stream, lead->ev_batch, 0));
+    }
+    for (int j = 0; j < k; j++) {
+        ctxs[j]->last_variant = 7;
+        ctxs[j]->last_handover = false;
+    }
+    return PAGK_OK;
 }
 
 // Tracking of (slot_ref, slot_cur) with the pyramid of ANOTHER frame (device image d_next) built into slot_next

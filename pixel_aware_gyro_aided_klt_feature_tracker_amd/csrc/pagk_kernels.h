@@ -252,26 +252,40 @@ __global__ void __launch_bounds__(256) k_gyro_predict(PredictArgs a)
 }
 
 // ---- shared epilogue: SetMatcher + DistortPoints for one feature --------------------------------
+// (the arrays a launch writes: the launch's own, or -- batched launches -- one camera stream's)
+struct OutPtrs {
+    float *pt_un, *pt_dist;
+    uint8_t *status;
+    double *pix_err, *dist_pred;
+    float *ncc;
+    int *iters;
+    const float *pred;  // mvPtPredictUn, or the reference points when there is no prediction (:384)
+};
+__device__ __forceinline__ void write_outputs_to(const TrackArgs &a, const OutPtrs &o, int i, float p2x, float p2y, int succ,
+                                                 float lastCost, int level0_ran, float ncc, int iters)
+{
+    o.pt_un[2 * i] = p2x;      // mvPtPredictAfterPatchMatchedUn  (:380)
+    o.pt_un[2 * i + 1] = p2y;
+    o.status[i] = (uint8_t)(level0_ran ? succ : 0);  // :351, :381 (zero-init when skipped)
+    if (o.pix_err) o.pix_err[i] = level0_ran ? sqrt((double)lastCost * a.win_size_inv) : 0.0;  // :352
+    if (o.dist_pred) {  // :384-385
+        float ddx = o.pred[2 * i] - p2x, ddy = o.pred[2 * i + 1] - p2y;
+        o.dist_pred[i] = (double)sqrtf(ddx * ddx + ddy * ddy);
+    }
+    if (o.pt_dist) {  // :116, :379
+        float ox, oy;
+        distort_point(a, p2x, p2y, ox, oy);
+        o.pt_dist[2 * i] = ox;
+        o.pt_dist[2 * i + 1] = oy;
+    }
+    if (o.ncc) o.ncc[i] = ncc;  // :365 / :95
+    if (o.iters) o.iters[i] = iters;
+}
 __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
                                               float lastCost, int level0_ran, float ncc, int iters)
 {
-    a.pt_un[2 * i] = p2x;      // mvPtPredictAfterPatchMatchedUn  (:380)
-    a.pt_un[2 * i + 1] = p2y;
-    a.status[i] = (uint8_t)(level0_ran ? succ : 0);  // :351, :381 (zero-init when skipped)
-    if (a.pix_err) a.pix_err[i] = level0_ran ? sqrt((double)lastCost * a.win_size_inv) : 0.0;  // :352
-    if (a.dist_pred) {  // :384-385
-        const float *pred = a.pt_init ? a.pt_init : a.pt_ref;
-        float ddx = pred[2 * i] - p2x, ddy = pred[2 * i + 1] - p2y;
-        a.dist_pred[i] = (double)sqrtf(ddx * ddx + ddy * ddy);
-    }
-    if (a.pt_dist) {  // :116, :379
-        float ox, oy;
-        distort_point(a, p2x, p2y, ox, oy);
-        a.pt_dist[2 * i] = ox;
-        a.pt_dist[2 * i + 1] = oy;
-    }
-    if (a.ncc) a.ncc[i] = ncc;  // :365 / :95
-    if (a.iters) a.iters[i] = iters;
+    const OutPtrs o{a.pt_un, a.pt_dist, a.status, a.pix_err, a.dist_pred, a.ncc, a.iters, a.pt_init ? a.pt_init : a.pt_ref};
+    write_outputs_to(a, o, i, p2x, p2y, succ, lastCost, level0_ran, ncc, iters);
 }
 
 // PatchMatch::NCC, src/patch_match.cpp:433-469, one thread.  Always on the level-0 images (:358,:361);

@@ -36,6 +36,9 @@ constexpr int kLvSeqStride = 1024;  // ints between the counters of two ticket s
 
 __device__ __forceinline__ void write_outputs(const TrackArgs &a, int i, float p2x, float p2y, int succ,
                                               float lastCost, int level0_ran, float ncc, int iters);
+struct OutPtrs;
+__device__ __forceinline__ void write_outputs_to(const TrackArgs &a, const OutPtrs &o, int i, float p2x, float p2y, int succ,
+                                                 float lastCost, int level0_ran, float ncc, int iters);
 __device__ __forceinline__ uint32_t lds_off(const void *p);
 
 // 9840 bytes: eight 1280-byte LDS granules, 16 waves per CU (with the accumulators in a member of their own the
@@ -63,6 +66,25 @@ static_assert(offsetof(QuadLds, ones) % 256 == 160 && sizeof(QuadLds) <= 8 * 128
 __host__ __device__ constexpr int quad_sq_row(int r) { return r * 129; }
 
 __device__ __forceinline__ double (*quad_acc(QuadLds &S))[16] { return reinterpret_cast<double (*)[16]>(&S.chunk[0][0][0]); }
+
+// A level description that was loaded from device memory (a batched launch's stream table), moved to scalar registers:
+// it is the same for every lane, but a load through a plain pointer comes back in vector registers, and nine of those
+// live across the whole level loop are nine spilled elsewhere.
+__device__ __forceinline__ DevLevel uniform_level(const DevLevel &v)
+{
+    DevLevel u;
+    const uint64_t q = (uint64_t)(uintptr_t)v.quad;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 32));
+    u.quad = reinterpret_cast<const uint32_t *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+    u.cols = __builtin_amdgcn_readfirstlane(v.cols);
+    u.rows = __builtin_amdgcn_readfirstlane(v.rows);
+    u.fcols = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.fcols)));
+    u.frows = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.frows)));
+    u.fcols_m1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.fcols_m1)));
+    u.frows_m1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.frows_m1)));
+    return u;
+}
 
 // Comment lines in the ISA that delimit the fence-free hand-offs; __graft_entry__.build() runs tools/isa_handoff.py over the
 // compiler's assembly and refuses a library in which what lies between them has lost its shape (agent scope on every
@@ -164,9 +186,16 @@ __device__ __forceinline__ void quad_read_system(QuadLds &S, int row, int P, dou
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
 #error "k_track_quad<.., LEVELS>: the level-to-level hand-off is written for gfx942 / gfx950 (see DESIGN.md section 4.3 (f))"
 #endif
-template <int NCH, bool LEAN = false, bool LEVELS = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
+// BATCH (with LEVELS; pagk_track_device_batch): ONE launch for several camera streams that share the device -- BASELINE
+// configs[4], "batched multi-camera".  The reference builds one PatchMatch per tracker (src/gyro_aided_tracker.cpp:276-283);
+// k trackers' calls are k independent feature sets over k image pairs, so their quads share one ticket space and one set
+// of ready lists: a quad knows its stream (a.batch[s]: both pyramids, the per-feature arrays), everything else is the
+// launch's.  Per stream the arithmetic is the stream's own launch's, hence the same bits.  No hand-over (a batch is a
+// launch of several rounds of resident waves, where the hand-over does not pay).
+template <int NCH, bool LEAN = false, bool LEVELS = false, bool BATCH = false>   // LEAN: no penalty, solver_variant 0 (see track_block_body)
 __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 {
+    static_assert(!BATCH || LEVELS, "the batched launch is a one-level-per-wave launch");
     __shared__ __attribute__((aligned(256))) QuadLds S;
     const int lane = threadIdx.x, row = lane >> 4, lr = lane & 15;
     int quad = (int)blockIdx.x, lv_step = 0;
@@ -202,7 +231,12 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
                     // the quads this wave -- and, for want of its hand-off, the waves below it -- will not track are
                     // unknown here, so the launch's status array is cleared by the first wave that gives up
                     if (lane == 0) st_agent(a.lv_error, 1);
-                    for (int k = lane; k < a.n; k += 64) a.status[k] = 0;
+                    if constexpr (BATCH) {
+                        for (int s = 0; s < a.batch_k; s++)
+                            for (int k = lane; k < a.batch[s].n; k += 64) a.batch[s].status[k] = 0;
+                    } else {
+                        for (int k = lane; k < a.n; k += 64) a.status[k] = 0;
+                    }
                     return;
                 }
                 __builtin_amdgcn_s_sleep(127);
@@ -239,17 +273,45 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     // patch geometry is a compile-time constant (divisions by the patch width, LDS addresses, chunk lengths)
     constexpr int h = NCH == 7 ? 10 : (NCH == 4 ? 7 : 5), Wd = 2 * h + 1, P = Wd * Wd;
     static_assert(NCH == 2 || NCH == 4 || NCH == 7, "instantiated for h = 5, 7, 10");
-    const int raw = 4 * quad + row;
-    const int fi = raw < a.n ? raw : a.n - 1;  // rows past the end shadow the last feature and write nothing
-    const bool live = raw < a.n && a.status_in[fi] != 0;
+    // the arrays of this quad's features: the launch's, or -- BATCH -- those of the camera stream the quad belongs to
+    // (wave-uniform: scalar loads).  Accessors, not local copies: a local copy of a kernel argument is loaded at once and
+    // lives in scalar registers from here on, and the non-batched kernel -- which sits at its register limit -- then
+    // spills one register more inside its loop (13 -> 14, +4 % run time; profiles/r04_ab3_batch_refactor_spill.log).
+    int quad_local = quad;
+    const BatchStream *bs = nullptr;
+    if constexpr (BATCH) {
+        int s = 0;
+        for (int k = 1; k < a.batch_k; k++) s = quad >= a.batch[k].quad_base ? k : s;   // (quad_base ascends)
+        bs = a.batch + s;
+        quad_local = quad - bs->quad_base;
+    }
+    auto v_pt_ref = [&]() -> const float * { if constexpr (BATCH) return bs->pt_ref; else return a.pt_ref; };
+    auto v_pt_init = [&]() -> const float * { if constexpr (BATCH) return bs->pt_init; else return a.pt_init; };
+    auto v_affine = [&]() -> const float * { if constexpr (BATCH) return bs->affine; else return a.affine; };
+    auto v_status_in = [&]() -> const uint8_t * { if constexpr (BATCH) return bs->status_in; else return a.status_in; };
+    auto v_n = [&]() -> int { if constexpr (BATCH) return bs->n; else return a.n; };
+    // `raw` / `fi` index those arrays; BATCH numbers the features through the whole launch as 4 * quad + row (lv_state;
+    // rows past a stream's end exist in that numbering and are never read)
+    const int raw = 4 * quad_local + row;
+    const int fi = raw < v_n() ? raw : v_n() - 1;  // rows past the end shadow the last feature and write nothing
+    const bool live = raw < v_n() && v_status_in()[fi] != 0;
+    auto emit_outputs = [&](int i, float ox, float oy, int osucc, float ocost, int ran, float oncc, int oiters) {
+        if constexpr (BATCH) {
+            const OutPtrs o{bs->pt_un, bs->pt_dist, bs->status, bs->pix_err, bs->dist_pred, bs->ncc, bs->iters,
+                            bs->pt_init ? bs->pt_init : bs->pt_ref};
+            write_outputs_to(a, o, i, ox, oy, osucc, ocost, ran, oncc, oiters);
+        } else {
+            write_outputs(a, i, ox, oy, osucc, ocost, ran, oncc, oiters);
+        }
+    };
 
-    const float *init = a.has_gyro ? a.pt_init : a.pt_ref;  // :85-89
+    const float *init = a.has_gyro ? v_pt_init() : v_pt_ref();  // :85-89
     float p2x = init[2 * fi], p2y = init[2 * fi + 1];
     float A00 = 1, A01 = 0, A10 = 0, A11 = 1;
     if (a.use_affine) {
-        A00 = a.affine[4 * fi], A01 = a.affine[4 * fi + 1], A10 = a.affine[4 * fi + 2], A11 = a.affine[4 * fi + 3];
+        A00 = v_affine()[4 * fi], A01 = v_affine()[4 * fi + 1], A10 = v_affine()[4 * fi + 2], A11 = v_affine()[4 * fi + 3];
     }
-    const float refx = a.pt_ref[2 * fi], refy = a.pt_ref[2 * fi + 1];
+    const float refx = v_pt_ref()[2 * fi], refy = v_pt_ref()[2 * fi + 1];
     const float fh = (float)h;
     const float ext_x = fabsf(A00) * fh + fabsf(A01) * fh + 2.0f;
     const float ext_y = fabsf(A10) * fh + fabsf(A11) * fh + 2.0f;
@@ -259,7 +321,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             wave_ended();
             return;
         }
-        if (lr == 0 && raw < a.n) write_outputs(a, fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
+        if (lr == 0 && raw < v_n()) emit_outputs(fi, p2x, p2y, 0, 0.0f, 0, 0.0f, 0);
         wave_ended();
         return;
     }
@@ -284,7 +346,7 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     if constexpr (LEVELS) {
         if (lv_step > 0) {  // take over from the item of the level above
             PAGK_HANDOFF_MARK("take-over begin");
-            const int *st = reinterpret_cast<const int *>(a.lv_state + 4 * (size_t)fi);
+            const int *st = reinterpret_cast<const int *>(a.lv_state + 4 * (size_t)(BATCH ? 4 * quad + row : fi));
             p2x = __int_as_float(ld_agent(st + 0)), p2y = __int_as_float(ld_agent(st + 1));
             iters = ld_agent(st + 2);
             susp = ld_agent(st + 3) != 0;  // handed to the latency kernel on a level above
@@ -309,8 +371,9 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
 #endif
 
     for (int level = level_first; level >= level_last; level--) {
-        const DevLevel &L1 = a.l1[level];
-        const DevLevel L2 = pin_level(a.l2[level]);
+        const DevLevel L1b = BATCH ? uniform_level(bs->l1[level]) : DevLevel();
+        const DevLevel &L1 = BATCH ? L1b : a.l1[level];
+        const DevLevel L2 = BATCH ? uniform_level(bs->l2[level]) : pin_level(a.l2[level]);
         const float ptx = refx * a.scales[level], pty = refy * a.scales[level];  // :177
         float nx, ny;
         if (level == a.n_levels - 1) {  // :180
@@ -519,8 +582,8 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
     if constexpr (LEVELS) {
         if (level_last > 0) {  // hand the quad to the next level: state, then the ready-list entry that publishes it
             PAGK_HANDOFF_MARK("state begin");
-            if (lr == 0 && raw < a.n) {
-                int *st = reinterpret_cast<int *>(a.lv_state + 4 * (size_t)fi);
+            if (lr == 0 && raw < v_n()) {
+                int *st = reinterpret_cast<int *>(a.lv_state + 4 * (size_t)(BATCH ? 4 * quad + row : fi));
                 st_agent(st + 0, __float_as_int(p2x)), st_agent(st + 1, __float_as_int(p2y)), st_agent(st + 2, iters);
                 st_agent(st + 3, susp ? 1 : 0);
             }
@@ -530,11 +593,11 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             return;
         }
     }
-    if (lr == 0 && raw < a.n && !susp) {
+    if (lr == 0 && raw < v_n() && !susp) {
         if (live)
-            write_outputs(a, fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)
+            emit_outputs(fi, p2x, p2y, succ, lastCost, 1, 1.0f, iters);  // :365 ncc = 1 (calc_ncc runs another variant)
         else
-            write_outputs(a, fi, init[2 * fi], init[2 * fi + 1], 0, 0.0f, 0, 0.0f, 0);
+            emit_outputs(fi, init[2 * fi], init[2 * fi + 1], 0, 0.0f, 0, 0.0f, 0);
     }
     wave_ended();
 }

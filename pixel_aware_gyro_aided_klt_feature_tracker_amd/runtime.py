@@ -377,3 +377,70 @@ class ResidentTracker:
         self.main.synchronize()
         self.side.synchronize()
         self.ctx.check_launch()
+
+
+class CameraBatch:
+    """k camera streams that share ONE GPU, stepped as one launch: BASELINE configs[4], "batched multi-camera: concurrent
+    streams, hipGraph-captured iterate".  The reference builds one PatchMatch per tracker
+    (src/gyro_aided_tracker.cpp:276-283); here every stream is a ResidentTracker (its own context: frame slots, feature
+    arrays, outputs), all switched to ONE stream, and a step is [the k current frames' pyramids, then
+    pagk_track_device_batch] -- replayed as one hipGraph after the first step, or issued directly."""
+
+    def __init__(self, params: capi.Params, k: int, device: int = 0):
+        self.params = params
+        self.cams = [ResidentTracker(params, device=device) for _ in range(k)]
+        self.stream = self.cams[0].main
+        for c in self.cams[1:]:
+            c.ctx.set_stream(self.stream.cuda_stream)   # one stream for the whole batch: nothing to order across streams
+        self._graph = None
+        self.mode_used = "serial"
+
+    def close(self):
+        self._drop_graph()
+        for c in self.cams:
+            c.close()
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            self.cams[0].ctx.graph_destroy(self._graph)
+            self._graph = None
+
+    def load(self, j: int, img_ref, img_cur, pt_ref, pt_init, affine, status_in):
+        """Stream j's frame pair and features (any image size, any feature count)."""
+        c = self.cams[j]
+        c.load_pair(img_ref, img_cur)
+        c.set_features(pt_ref, pt_init, affine, status_in)
+        c.ctx.set_stream(self.stream.cuda_stream)
+        self._drop_graph()
+
+    def _issue(self):
+        for c in self.cams:
+            c.rebuild_current_pyramid(1)
+        cs = self.cams
+        capi.Context.track_device_batch([c.ctx for c in cs], self.params, [0] * len(cs), [1] * len(cs),
+                                        [c.hi - c.lo for c in cs], [c.d_pt_ref for c in cs], [c.d_pt_init for c in cs],
+                                        [c.d_affine for c in cs], [c.d_status for c in cs], [c.out for c in cs])
+
+    def step(self, mode: str = "graph"):
+        """One frame of every stream; returns the streams' output dicts (device tensors, valid once `stream` has run)."""
+        lead = self.cams[0].ctx
+        with torch.cuda.stream(self.stream):
+            if mode == "graph":
+                if self._graph is None:
+                    self._issue()                      # warm-up: allocations happen outside the capture
+                    self.stream.synchronize()
+                    lead.graph_begin()
+                    try:
+                        self._issue()
+                    finally:
+                        self._graph = lead.graph_end()
+                lead.graph_launch(self._graph)
+            else:
+                self._issue()
+        self.mode_used = mode
+        return [c.out for c in self.cams]
+
+    def synchronize(self):
+        self.stream.synchronize()
+        for c in self.cams:
+            c.ctx.check_launch()

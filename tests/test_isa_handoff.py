@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import isa_handoff  # noqa: E402
 
 GOOD = """
-_ZN4pagk12k_track_quadILi7ELb1ELb1EEEvNS_9TrackArgsE: ; @kernel
+_ZN4pagk12k_track_quadILi7ELb1ELb1ELb0EEEvNS_9TrackArgsE: ; @kernel
 	global_atomic_add v3, v3, v4, s[34:35] sc0
 	s_waitcnt vmcnt(0)
 .LBB0_1:

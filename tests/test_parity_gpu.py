@@ -623,6 +623,103 @@ def test_config4_eight_concurrent_streams_on_one_gpu(ctx, hint, variant):
         rt.close()
 
 
+def _ragged_streams():
+    """Camera streams that differ in everything a batch may differ in: image size, feature count (one not a multiple of
+    four, one zero, one single feature), seed."""
+    shapes = [(1280, 720, 4000), (640, 480, 1501), (752, 480, 2002), (320, 240, 0), (1280, 720, 3999), (640, 480, 1),
+              (1920, 1080, 2500), (752, 480, 777)]
+    ws = []
+    for j, (wd, ht, n) in enumerate(shapes):
+        w = synth.make_workload(f"batch{j}", wd, ht, max(n, 1), seed=0x5EED0B00 + j, half_patch=10, iterations=30, pyramids=3,
+                                edge_fraction=0.05)
+        ws.append((w, n))
+    return ws
+
+
+@pytest.mark.parametrize("mode", ["serial", "graph"])
+def test_batched_multi_camera_launch_equals_every_streams_own_launch(ctx, mode):
+    """pagk_track_device_batch (BASELINE configs[4], "batched multi-camera"): eight ragged camera streams as ONE launch of
+    variant 7 whose quads carry their stream -- every stream must get the bits of its own launch (which other tests hold
+    to the oracle), issued directly and as a replayed hipGraph (two frames each, the second with new feature values)."""
+    ws = _ragged_streams()
+    p = params_for(ws[0][0])
+    own = []
+    for w, n in ws:
+        own.append(ctx.track(p, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n]) if n else None)
+    cb = runtime.CameraBatch(p, len(ws), device=0)
+    try:
+        for j, (w, n) in enumerate(ws):
+            cb.load(j, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n])
+        outs = None
+        for _ in range(2):
+            outs = cb.step(mode=mode)
+        cb.synchronize()
+        assert cb.mode_used == mode and cb.cams[0].ctx.last_variant() == 7
+        for j, ((w, n), out) in enumerate(zip(ws, outs)):
+            if n == 0:
+                continue
+            got = distributed.to_numpy(out)
+            assert_parity(got, own[j], n, exact=True, what=f"stream {j} of the batch ({mode})")
+        # and against the oracle itself for two of the streams
+        for j in (1, 7):
+            w, n = ws[j]
+            ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n], nthreads=8)
+            assert_parity(distributed.to_numpy(outs[j]), ref, n, exact=True, what=f"stream {j} of the batch vs the oracle")
+    finally:
+        cb.close()
+
+
+def test_small_batches_and_ncc_batches_run_as_their_own_launches(ctx):
+    """Below the level kernel's threshold (and with calculate_ncc, which that kernel does not compute) a batch is k
+    launches on the streams' own contexts: same entry point, same results."""
+    ws = _ragged_streams()[1:4]      # 1501 + 2002 + 0 features: under 6000
+    for ncc in (False, True):
+        p = params_for(ws[0][0], ncc=ncc)
+        cb = runtime.CameraBatch(p, len(ws), device=0)
+        try:
+            for j, (w, n) in enumerate(ws):
+                cb.load(j, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n])
+            outs = cb.step(mode="serial")
+            cb.synchronize()
+            assert cb.cams[0].ctx.last_variant() == 0
+            for j, ((w, n), out) in enumerate(zip(ws, outs)):
+                if n:
+                    own = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n])
+                    assert_parity(distributed.to_numpy(out), own, n, exact=True, what=f"small batch, stream {j}, ncc {ncc}")
+        finally:
+            cb.close()
+
+
+def test_a_live_graph_keeps_library_buffers_from_moving(ctx):
+    """an instantiated graph holds pointers into the level kernel's workspaces; a later, larger direct launch
+    must not reallocate them under it (PAGK_E_ARG until the graph is destroyed)."""
+    w = synth.config(3, n=16000)
+    p = params_for(w)
+    rt = runtime.ResidentTracker(p, device=0)
+    try:
+        rt.load_pair(w.img_ref, w.img_cur)
+        half = w.n // 2
+        rt.set_features(w.pt_ref[:half], w.pt_init[:half], w.affine[:half], w.status_in[:half])
+        rt.step(mode="graph")
+        rt.step(mode="graph")
+        rt.synchronize()
+        assert rt.mode_used == "graph" and rt.ctx.last_variant() == 7
+        gid = rt._graphs["graph"][0]
+        big = distributed.alloc_device_outputs(w.n, rt.dev)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(rt.dev)   # noqa: E731
+        args = (p, 0, 1, w.n, d(w.pt_ref), d(w.pt_init), d(w.affine), d(w.status_in), big)
+        with pytest.raises(capi.PagkError) as e:
+            rt.ctx.track_device(*args)
+        assert e.value.code == capi.PAGK_E_ARG and "graph" in str(e.value)
+        rt.ctx.graph_launch(gid)          # the graph still replays into intact buffers
+        rt.synchronize()
+        rt._drop_graph()
+        rt.ctx.track_device(*args)        # and without it the larger launch goes through
+        rt.synchronize()
+    finally:
+        rt.close()
+
+
 def test_config3_direct_and_graph_steps_with_and_without_hand_over(ctx, monkeypatch):
     """BASELINE configs[3] on one GPU: the automatic choice is four features per wave, one level per wave (variant 7),
     and a direct launch hands features past the iteration budget to the latency kernel running beside it (automatic

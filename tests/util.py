@@ -35,7 +35,7 @@ def load_golden(name):
 def params_for(w, **kw):
     return capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                             camera=w.camera, illumination=kw.get("illumination", True), affine=kw.get("affine", True),
-                            penalty=kw.get("penalty", w.penalty))
+                            penalty=kw.get("penalty", w.penalty), ncc=kw.get("ncc", False))
 
 
 def assert_parity(got, ref, n, status_in=None, exact=True, what=""):

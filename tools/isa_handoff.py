@@ -20,7 +20,8 @@ Every instantiation with LEVELS = true must contain each region at least once.  
 import re
 import sys
 
-KERNEL = re.compile(r"^(_ZN4pagk12k_track_quadILi\d+ELb[01]ELb1EEEvNS_9TrackArgsE):")
+# k_track_quad<NCH, LEAN, LEVELS = true, BATCH>
+KERNEL = re.compile(r"^(_ZN4pagk12k_track_quadILi\d+ELb[01]ELb1ELb[01]EEEvNS_9TrackArgsE):")
 MEM = re.compile(r"^\s*(global_|buffer_|flat_|scratch_)")
 
 
@@ -64,7 +65,7 @@ def check(asm_text):
     if not ks:
         return ["no k_track_quad<.., LEVELS = true> instantiation in the assembly"]
     for k, body in ks.items():
-        where = k[len("_ZN4pagk12"):len("_ZN4pagk12") + 28]
+        where = k[len("_ZN4pagk12"):len("_ZN4pagk12") + 32]
 
         def no_fence(region, what):
             for ins in region:
