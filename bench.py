@@ -361,6 +361,14 @@ def main() -> int:
     # step is replayed for a fixed wall time first (synchronised every 20 steps: a deep launch backlog has its own
     # after-effect), THEN the W warm-up steps and the K timed steps follow exactly as the contract says.
     spinup_s = float(os.environ.get("PAGK_BENCH_SPINUP_S", "0.5"))
+    # ... and the contract-pure figure beside it: the SAME W warm-up + K timed steps taken first, on the device as this
+    # fresh process found it (`ms_per_step_cold` / `value_cold` in the line).  `value` is the
+    # steady-state figure and the one compared between rounds; BASELINE.md holds no published number for either.
+    elapsed_cold, _ = time_steps(rt, args.steps, args.warmup, step_mode, barrier)
+    if world > 1:
+        t = torch.tensor([elapsed_cold], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_cold = float(t.item())
     if spinup_s > 0:
         def burst(k):
             for _ in range(k):
@@ -393,6 +401,7 @@ def main() -> int:
     variant = rt.ctx.last_variant()
     res = distributed.to_numpy(out)  # full length on every rank (gathered when world > 1)
 
+    rt.ctx.check_launch()   # (torch synchronised the streams, not pagk_sync: read the launches' error word)
     extras = {}
     if (world > 1 or force_dist) and not replicas:
         # the collective by itself (events on the stream it runs on), and the same steps without it
@@ -400,6 +409,43 @@ def main() -> int:
         extras["gather"]["via"] = gather_via
         t_nog, _ = time_steps(rt, max(10, args.steps // 4), 3, step_mode + "-nogather", barrier)
         extras["gather"]["ms_per_step_without_gather"] = t_nog / max(10, args.steps // 4) * 1e3
+        # what RCCL itself says the gather spans (ncclCommCount of the library's communicator), beside torch's world size
+        extras["gather"]["rccl_ranks"] = comm.comm_count() if comm is not None else None
+        extras["gather"]["torch_world"] = world
+        # the gathered result against ONE unsharded launch of the same features on rank 0's own GPU (its own context,
+        # host buffers in, results out): the sharded path must reproduce it bit for bit -- the proof, inside the line, that
+        # what N GPUs gathered is what one GPU computes
+        if rank == 0:
+            sctx = capi.Context(local_rank)
+            single = sctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+            sctx.close()
+            n = w.n
+            d = np.abs(res["pt_un"][:n].astype(np.float64) - single["pt_un"][:n].astype(np.float64))
+            extras["px_err_vs_single"] = {
+                "max": float(d.max()) if d.size else 0.0,
+                "status_mismatches": int(np.count_nonzero(res["status"][:n] != single["status"][:n])),
+                "pix_err_mismatches": int(np.count_nonzero(res["pix_err"][:n] != single["pix_err"][:n])),
+                "compared": int(n),
+                "what": f"all-gathered result of {world} rank(s) vs one unsharded pagk_track of the same {n} features on rank 0's GPU"}
+    if replicas:
+        # every stream's own check (no collective on the data path, so nothing else ties the ranks' results to anything):
+        # the first 256 features re-tracked by the reference-shaped one-thread-per-feature kernel (pagk_set_kernel 1, an
+        # independent device implementation of the loop nest) on the same GPU; gathered for the line over the control plane
+        m = min(256, w.n)
+        cctx = capi.Context(local_rank)
+        cctx.set_kernel(1)
+        chk = cctx.track(p, w.img_ref, w.img_cur, w.pt_ref[:m].copy(), w.pt_init[:m].copy(), w.affine[:m].copy(), w.status_in[:m].copy())
+        cctx.close()
+        dd = np.abs(res["pt_un"][:m].astype(np.float64) - chk["pt_un"][:m].astype(np.float64))
+        mine_chk = torch.tensor([float(dd.max()) if dd.size else 0.0, float(np.count_nonzero(res["status"][:m] != chk["status"][:m])), float(m)],
+                                dtype=torch.float64, device="cuda")
+        allc = [mine_chk]
+        if world > 1:
+            allc = [torch.zeros_like(mine_chk) for _ in range(world)]
+            dist.all_gather(allc, mine_chk)
+        extras["per_stream_check"] = {
+            "what": "per GPU: its stream's first features vs the one-thread-per-feature kernel on the same GPU",
+            "streams": [{"max_px": float(v[0].item()), "status_mismatches": int(v[1].item()), "compared": int(v[2].item())} for v in allc]}
     if rank == 0 and world == 1 and not args.no_extras:
         # the look-ahead step beside the headline, and how the two launches can reach the GPU
         ksteps = max(20, args.steps // 2)
@@ -464,6 +510,7 @@ def main() -> int:
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if replicas else args.scaling, "vs_baseline": None,
             "per_gpu_ms_per_step": per_gpu_ms,
+            "ms_per_step_cold": elapsed_cold / args.steps * 1e3, "value_cold": n_active_total * args.steps / elapsed_cold,
             "dtype": "f32 sampling, f64 normal equations", "data": "synthetic", "spinup_s": spinup_s,
             "config": {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} pair, "
                                    f"{n_total * world if replicas else n_total} keypoints "

@@ -398,6 +398,9 @@ int pagk_multi_create_rank(pagk_multi **out, const uint8_t id[128], int32_t rank
 void pagk_multi_destroy(pagk_multi *pm);
 int32_t pagk_multi_world(const pagk_multi *pm);  /* ranks of the group                        */
 int32_t pagk_multi_local(const pagk_multi *pm);  /* ranks driven by this process              */
+int32_t pagk_multi_comm_count(const pagk_multi *pm); /* ncclCommCount of the group's communicator: the ranks RCCL itself
+                                                        reports (a benchmark line's proof that the gather spans N GPUs);
+                                                        negative when unavailable */
 pagk_ctx *pagk_multi_ctx(pagk_multi *pm, int32_t local_index);  /* owned by the group; do not pagk_destroy */
 const char *pagk_multi_last_error(const pagk_multi *pm);
 /* The partition and the layout of a rank's packed result slice for m = ceil(n / G) features: seven SoA blocks in

@@ -230,6 +230,9 @@ def declare(lib) -> None:
     lib.pagk_multi_destroy.argtypes = [vp]
     lib.pagk_multi_world.restype = i32
     lib.pagk_multi_world.argtypes = [vp]
+    if hasattr(lib, "pagk_multi_comm_count"):
+        lib.pagk_multi_comm_count.restype = i32
+        lib.pagk_multi_comm_count.argtypes = [vp]
     lib.pagk_multi_local.restype = i32
     lib.pagk_multi_local.argtypes = [vp]
     lib.pagk_multi_ctx.restype = vp
@@ -259,6 +262,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
     "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch",
+    "pagk_multi_comm_count",
 ]
 
 
@@ -655,6 +659,11 @@ class Multi:
         self.world = self.lib.pagk_multi_world(h)
         self.n_local = self.lib.pagk_multi_local(h)
         self.rank = rank if uid is not None else 0
+
+    def comm_count(self) -> int | None:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount); None when the library cannot tell."""
+        c = int(self.lib.pagk_multi_comm_count(self.h))
+        return c if c >= 0 else None
 
     @staticmethod
     def unique_id() -> bytes:

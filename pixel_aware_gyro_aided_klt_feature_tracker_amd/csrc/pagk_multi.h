@@ -35,6 +35,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;                        // ncclCommCount(comm, &count) (optional)
 };
 
 void rccl_load_once(Rccl &r, char *err, size_t errn)
@@ -58,6 +59,7 @@ void rccl_load_once(Rccl &r, char *err, size_t errn)
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     if (!r.GetUniqueId || !r.CommInitAll || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart ||
         !r.GroupEnd) {
         snprintf(err, errn, "librccl.so lacks a required entry point");
@@ -132,6 +134,15 @@ size_t pagk_shard_layout(int32_t m, size_t offsets[7])
 const char *pagk_multi_last_error(const pagk_multi *pm) { return pm ? pm->err : ""; }
 int32_t pagk_multi_world(const pagk_multi *pm) { return pm ? pm->world : 0; }
 int32_t pagk_multi_local(const pagk_multi *pm) { return pm ? pm->n_local : 0; }
+// What RCCL itself says about the group: ncclCommCount of local member 0's communicator (the ranks the all-gather
+// really spans), as opposed to the number the group was created with.  < 0: unavailable.
+int32_t pagk_multi_comm_count(const pagk_multi *pm)
+{
+    if (!pm || !pm->rccl || !pm->rccl->CommCount || pm->comm.empty() || !pm->comm[0]) return PAGK_E_NCCL;
+    int count = -1;
+    if (pm->rccl->CommCount(pm->comm[0], &count) != 0) return PAGK_E_NCCL;
+    return count;
+}
 pagk_ctx *pagk_multi_ctx(pagk_multi *pm, int32_t local_index)
 {
     return (pm && local_index >= 0 && local_index < pm->n_local) ? pm->ctx[local_index] : nullptr;
