@@ -302,7 +302,13 @@ int pagk_selftest_repeat_sum(pagk_ctx *ctx, int32_t n, const float *c, int32_t c
  * (nothing may allocate during capture); host-buffer and synchronising entry points return PAGK_E_ARG while
  * capturing; the context stream must not be the legacy default stream; the kernel timers
  * (pagk_last_kernel_ms) do not see replays.  Up to 8 graphs per context.  The reference has no counterpart:
- * its per-frame loop is Examples/Demo/RealSenseD435i.cpp:199-321. */
+ * its per-frame loop is Examples/Demo/RealSenseD435i.cpp:199-321.
+ * A captured pagk_track_device that hands its stragglers to the latency kernel (kernels 5 / 7 on large launches) is
+ * replayed in SEGMENTS: HIP replays the parallel branches of one graph one after the other, and that kernel has to run
+ * beside the throughput kernel, so the capture is closed in front of it, the finisher becomes a plain launch on the
+ * context's auxiliary stream, and the capture reopens -- pagk_graph_launch then issues graph, finisher, graph, graph.
+ * Same results, and the replayed step is as fast as the direct one (BASELINE configs[3]: 0.57 ms either way).  Such a
+ * capture must not have forked other streams into itself at that point. */
 int pagk_graph_begin(pagk_ctx *ctx);
 int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id);
 int pagk_graph_launch(pagk_ctx *ctx, int32_t graph_id);

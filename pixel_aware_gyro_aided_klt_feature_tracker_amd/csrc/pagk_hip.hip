@@ -80,6 +80,21 @@ struct pagk_ctx {
     static constexpr int kGraphs = 8;
     hipGraph_t graphs[kGraphs] = {};
     hipGraphExec_t graph_execs[kGraphs] = {};
+    // A captured step that contains a launch with the LIVE finisher is replayed in segments (round 4): HIP replays the
+    // parallel branches of one graph one after the other, so the finisher -- which must run BESIDE the throughput kernel --
+    // is not a node: the capture is closed in front of that kernel, the finisher is remembered as a plain launch on the
+    // auxiliary stream, the capture reopens.  graph_execs[k] is the LAST segment; pre_segs[k] what runs before it.
+    struct GraphSeg {
+        enum Kind { GRAPH, FINISHER, JOIN } kind = GRAPH;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ex = nullptr;
+        const void *fn = nullptr;   // FINISHER: k_track_resume_live<..>, its arguments and launch shape
+        TrackArgs args;
+        int grid = 0;
+        size_t lds = 0;
+    };
+    std::vector<GraphSeg> pre_segs[kGraphs];
+    std::vector<GraphSeg> cap_segs;   // segments closed so far in the capture that is open
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
     int kernel = 0;
@@ -147,6 +162,41 @@ bool in_capture(pagk_ctx *ctx)
     if (ctx->capturing) return true;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+}
+
+// Close the open capture segment of pagk_graph_begin (what was recorded so far becomes one instantiated graph in
+// ctx->cap_segs) and open the next one.  Used around a launch whose finisher must not be a graph node.
+int capture_split(pagk_ctx *ctx)
+{
+    hipGraph_t g = nullptr;
+    HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &g));
+    if (g) {
+        pagk_ctx::GraphSeg seg;
+        hipError_t e = hipGraphInstantiate(&seg.ex, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(g);
+            ctx->capturing = false;
+            snprintf(ctx->err, sizeof(ctx->err), "hipGraphInstantiate (segment) -> %s", hipGetErrorString(e));
+            return PAGK_E_HIP;
+        }
+        seg.g = g;
+        ctx->cap_segs.push_back(seg);
+    }
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        ctx->capturing = false;
+        snprintf(ctx->err, sizeof(ctx->err), "hipStreamBeginCapture (next segment) -> %s", hipGetErrorString(e));
+        return PAGK_E_HIP;
+    }
+    return PAGK_OK;
+}
+void destroy_segs(std::vector<pagk_ctx::GraphSeg> &v)
+{
+    for (auto &sg : v) {
+        if (sg.ex) (void)hipGraphExecDestroy(sg.ex);
+        if (sg.g) (void)hipGraphDestroy(sg.g);
+    }
+    v.clear();
 }
 
 int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
@@ -361,8 +411,10 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
     const bool exposed_tail = 100ll * waves > 45 * cap && 100ll * waves <= 125 * cap;
     // (not inside a graph capture: the replayed graph runs its two branches one after the other, measured, and a
     // finisher that starts after the throughput kernel is the plain sweep: +13 %)
-    // (the caller's own capture of the stream, not through pagk_graph_begin, counts as well: in_capture)
-    if (ctx->concurrency != 1 || !exposed_tail || in_capture(ctx)) return 0;
+    // (not inside a capture of the stream that is not ours -- the host application's own hipStreamBeginCapture: a replayed
+    // graph runs a finisher branch AFTER the throughput kernel, +13 %.  pagk_graph_begin's capture is replayed in
+    // segments with the finisher beside the kernel, like a direct launch)
+    if (ctx->concurrency != 1 || !exposed_tail || (in_capture(ctx) && !ctx->capturing)) return 0;
     return 20;
 }
 
@@ -379,13 +431,16 @@ int quad_budget_for(pagk_ctx *ctx, int waves, int iterations, int levels, int ha
 // profiles/r03_levels_sweep_only.log): in a capture, up to 1.25 rounds.
 int levels_budget_for(pagk_ctx *ctx, int quads, int iterations, int levels, int half, bool *live)
 {
-    const bool captured = in_capture(ctx);
-    *live = !captured || ctx->quad_budget >= 0;   // (a forced budget keeps the parallel branch: tests)
+    // a capture of the stream that is not pagk_graph_begin's (the host application's own): its replay runs a finisher
+    // branch after the kernel, so there the hand-over is the sweep alone, up to 1.25 rounds.  Our own capture is replayed
+    // in segments with the finisher beside the kernel (launch_track): the direct launch's rule.
+    const bool foreign = in_capture(ctx) && !ctx->capturing;
+    *live = !foreign || ctx->quad_budget >= 0;   // (a forced budget keeps the parallel branch: tests)
     if (ctx->quad_budget >= 0) return ctx->quad_budget;
     if (iterations * levels < 60 || ctx->concurrency != 1) return 0;
     const long long cap = quad_capacity(ctx, half);
     if (100ll * quads <= 45 * cap) return 0;
-    if (captured && 100ll * quads > 125 * cap) return 0;
+    if (foreign && 100ll * quads > 125 * cap) return 0;
     return 20;
 }
 
@@ -600,7 +655,16 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             // the live finisher runs beside the throughput kernel, on the context's auxiliary stream (inside a graph
             // capture the auxiliary stream joins the capture through the fork event: a parallel branch of the graph)
             const bool live = handover && live_ok && ctx->finisher_wgs > 0 && ctx->aux_stream;
-            if (live) {
+            // inside pagk_graph_begin's capture the finisher is not a node of the graph but a launch of its own between
+            // two segments of it (see pagk_ctx::GraphSeg); PAGK_GRAPH_BRANCH=1 keeps the old parallel-branch form (tests)
+            const bool segmented = live && ctx->capturing && !getenv("PAGK_GRAPH_BRANCH");
+            int fin_seg = -1;
+            if (segmented) {
+                if (int sr = capture_split(ctx)) return sr;
+                ctx->cap_segs.emplace_back();
+                ctx->cap_segs.back().kind = pagk_ctx::GraphSeg::FINISHER;   // (filled in below, once its arguments exist)
+                fin_seg = (int)ctx->cap_segs.size() - 1;
+            } else if (live) {
                 HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
             }
@@ -626,6 +690,14 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             if (live) {
                 const size_t lds = track_block_lds_bytes(a.half);
                 auto finisher = [&](auto kern) -> hipError_t {
+                    if (segmented) {   // remembered, not launched: pagk_graph_launch issues it beside the kernel's segment
+                        pagk_ctx::GraphSeg &fs = ctx->cap_segs[(size_t)fin_seg];
+                        fs.fn = reinterpret_cast<const void *>(kern);
+                        fs.args = af;
+                        fs.grid = ctx->finisher_wgs;
+                        fs.lds = lds;
+                        return hipSuccess;
+                    }
                     hipLaunchKernelGGL(kern, dim3(ctx->finisher_wgs), dim3(kBlock), lds, ctx->aux_stream, af);
                     return hipGetLastError();
                 };
@@ -633,8 +705,16 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 else if (a.half == 7) e = lean ? finisher(k_track_resume_live<1, 1, true>) : finisher(k_track_resume_live<1, 1>);
                 else e = lean ? finisher(k_track_resume_live<2, 25, true>) : finisher(k_track_resume_live<2, 25>);
                 HIPCHK(ctx, e);
-                HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                if (segmented) {
+                    // the kernel's own segment ends here; what follows (the sweep, whatever the caller records next) waits
+                    // for the finisher at replay
+                    if (int sr = capture_split(ctx)) return sr;
+                    ctx->cap_segs.emplace_back();
+                    ctx->cap_segs.back().kind = pagk_ctx::GraphSeg::JOIN;
+                } else {
+                    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                }
             }
             if (handover) {
                 // the sweep: the latency kernel finishes what is still waiting in the list (a fixed grid walks it)
@@ -993,11 +1073,14 @@ void pagk_destroy(pagk_ctx *ctx)
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (int k = 0; k < pagk_ctx::kGraphs; k++)
+    for (int k = 0; k < pagk_ctx::kGraphs; k++) {
         if (ctx->graph_execs[k]) {
             (void)hipGraphExecDestroy(ctx->graph_execs[k]);
             (void)hipGraphDestroy(ctx->graphs[k]);
         }
+        destroy_segs(ctx->pre_segs[k]);
+    }
+    destroy_segs(ctx->cap_segs);
     for (auto &s : ctx->slots)
         if (s.block) (void)hipFree(s.block);
     if (ctx->feat.block) (void)hipFree(ctx->feat.block);
@@ -1582,6 +1665,7 @@ int pagk_graph_begin(pagk_ctx *ctx)
 {
     if (!ctx || ctx->capturing) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    destroy_segs(ctx->cap_segs);
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
     return PAGK_OK;
@@ -1601,6 +1685,7 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
         }
     if (id < 0 || !g) {
         if (g) (void)hipGraphDestroy(g);
+        destroy_segs(ctx->cap_segs);
         snprintf(ctx->err, sizeof(ctx->err), id < 0 ? "all %d graph slots are in use" : "capture produced no graph (%d)", pagk_ctx::kGraphs);
         return PAGK_E_ARG;
     }
@@ -1608,11 +1693,14 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
     hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g);
+        destroy_segs(ctx->cap_segs);
         snprintf(ctx->err, sizeof(ctx->err), "hipGraphInstantiate -> %s", hipGetErrorString(e));
         return PAGK_E_HIP;
     }
     ctx->graphs[id] = g;
     ctx->graph_execs[id] = ex;
+    ctx->pre_segs[id] = std::move(ctx->cap_segs);   // (empty for a capture without a live finisher: one graph, as before)
+    ctx->cap_segs.clear();
     *graph_id = id;
     return PAGK_OK;
 }
@@ -1620,6 +1708,20 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
 int pagk_graph_launch(pagk_ctx *ctx, int32_t graph_id)
 {
     if (!ctx || ctx->capturing || graph_id < 0 || graph_id >= pagk_ctx::kGraphs || !ctx->graph_execs[graph_id]) return PAGK_E_ARG;
+    for (pagk_ctx::GraphSeg &sg : ctx->pre_segs[graph_id]) {
+        if (sg.kind == pagk_ctx::GraphSeg::GRAPH) {
+            HIPCHK(ctx, hipGraphLaunch(sg.ex, ctx->stream));
+        } else if (sg.kind == pagk_ctx::GraphSeg::FINISHER) {
+            // the live finisher beside the throughput kernel of the next segment: the fork of a direct launch
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            void *kargs[] = {&sg.args};
+            HIPCHK(ctx, hipLaunchKernel(sg.fn, dim3(sg.grid), dim3(kBlock), kargs, sg.lds, ctx->aux_stream));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        } else {
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+    }
     HIPCHK(ctx, hipGraphLaunch(ctx->graph_execs[graph_id], ctx->stream));
     return PAGK_OK;
 }
@@ -1628,8 +1730,10 @@ int pagk_graph_destroy(pagk_ctx *ctx, int32_t graph_id)
 {
     if (!ctx || graph_id < 0 || graph_id >= pagk_ctx::kGraphs || !ctx->graph_execs[graph_id]) return PAGK_E_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->aux_stream));
     (void)hipGraphExecDestroy(ctx->graph_execs[graph_id]);
     (void)hipGraphDestroy(ctx->graphs[graph_id]);
+    destroy_segs(ctx->pre_segs[graph_id]);
     ctx->graph_execs[graph_id] = nullptr;
     ctx->graphs[graph_id] = nullptr;
     return lv_check(ctx);
