@@ -250,8 +250,12 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
             if (wave < 2) {
                 // ---- ordered accumulation (:284-299), the feature's critical path: wins issue arbitration ----------
                 __builtin_amdgcn_s_setprio(3);
-                const double s = chain_rows_f64_piped<H>(row_addr, row_s1, flag_addr, (uint32_t)((HAS_B ? 2 : 1) * seq),
-                                                         (uint32_t)seq);
+                // (the iteration number is the same in every lane, but the loop's exits depend on values read from LDS, so the
+                // compiler may carry it in a vector register -- and an "s" operand of inline asm is taken as is: seen when
+                // this body was instantiated inside another kernel, profiles/r04_lead_pyramid_experiment.patch)
+                const uint32_t seq_ab = (uint32_t)__builtin_amdgcn_readfirstlane((HAS_B ? 2 : 1) * seq);
+                const uint32_t seq_c = (uint32_t)__builtin_amdgcn_readfirstlane(seq);
+                const double s = chain_rows_f64_piped<H>(row_addr, row_s1, flag_addr, seq_ab, seq_c);
                 if (acc_slot >= 0) acc[acc_slot] = s;
                 if (wave == 1) {
                     // the flag right behind the sums: LDS executes one wave's instructions in order, so whoever reads the
@@ -379,7 +383,8 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     STAMP(10)   // (wave 3) B1 -> batch B published
                 }
                 __builtin_amdgcn_s_setprio(1);
-                const float c = chain_rows_f32_piped<H>(row_addr, flag_addr, (uint32_t)((HAS_B ? 2 : 1) * seq), (uint32_t)seq);
+                const float c = chain_rows_f32_piped<H>(row_addr, flag_addr, (uint32_t)__builtin_amdgcn_readfirstlane((HAS_B ? 2 : 1) * seq),
+                                                        (uint32_t)__builtin_amdgcn_readfirstlane(seq));
                 if (lane == 0) sh_cost[0] = c;
                 STAMP(13)   // (wave 3) B published -> cost published
                 __builtin_amdgcn_s_setprio(0);
