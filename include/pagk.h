@@ -225,6 +225,10 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream);
  *     resident wavefronts, which otherwise end with most of the device idle.  Bit-identical like 0-3.  With one
  *     pyramid level, or calc_ncc, it is 5. */
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which);
+/* Variants 2 and 6 no longer win at any launch size and nothing selects them automatically; the product's build leaves
+ * them out (pagk_set_kernel returns PAGK_E_UNSUPPORTED for them) and a library compiled with -DPAGK_ALL_VARIANTS carries
+ * them for cross-checks.  1 = `which` can be selected in this build. */
+int pagk_has_variant(int32_t which);
 /* The variant (numbering above; 0 = the 4-wave kernel) the last tracking launch of this context actually used;
  * -1 before the first launch. */
 int pagk_last_variant(const pagk_ctx *ctx);

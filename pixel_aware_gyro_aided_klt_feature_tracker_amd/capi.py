@@ -262,7 +262,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
     "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch",
-    "pagk_multi_comm_count",
+    "pagk_multi_comm_count", "pagk_has_variant",
 ]
 
 
@@ -278,6 +278,16 @@ def load():
         declare(lib)
         _lib = lib
     return _lib
+
+
+def has_variant(which: int) -> bool:
+    """Can pagk_set_kernel select `which` in the library that is loaded?  (Variants 2 and 6 need -DPAGK_ALL_VARIANTS.)"""
+    lib = load()
+    if not hasattr(lib, "pagk_has_variant"):
+        return True   # (an older build, loaded for an A/B run)
+    lib.pagk_has_variant.restype = C.c_int
+    lib.pagk_has_variant.argtypes = [C.c_int32]
+    return bool(lib.pagk_has_variant(int(which)))
 
 
 class PagkError(RuntimeError):

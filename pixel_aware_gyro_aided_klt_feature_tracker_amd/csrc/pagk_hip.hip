@@ -514,7 +514,11 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         // compile-time facts (LEAN); everything else runs the generic instantiations
         const bool lean = !a.penalty && a.solver == 0;
         const long long n_sel = (long long)n * ctx->concurrency;  // what the automatic thresholds are applied to
+#ifdef PAGK_ALL_VARIANTS
         const bool use_rows = mfma_ok && !a.calc_ncc && a.iterations >= 1 && ctx->kernel == 6;
+#else
+        const bool use_rows = false;   // (variant (e) is not in this build: pagk_set_kernel(ctx, 6) was refused)
+#endif
         // four features per wave, one level per wave (needs more than one level to differ from the quad kernel)
         const bool use_levels = mfma_ok && !a.calc_ncc && p->pyramids >= 2 && ctx->lv_error &&
                                 (ctx->kernel == 7 || (ctx->kernel == 0 && (ctx->concurrency == 1 || ctx->levels_shared) &&
@@ -522,10 +526,15 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
         const bool quad_like = ctx->kernel == 5 || ctx->kernel == 6 || ctx->kernel == 7;
         const bool use_quad = !use_rows && !use_levels && mfma_ok && !a.calc_ncc && (quad_like || (ctx->kernel == 0 && n_sel >= ctx->quad_min_features));
         const bool use_wave = !use_quad && !use_rows && !use_levels && mfma_ok && (ctx->kernel == 3 || quad_like || (ctx->kernel == 0 && n_sel >= ctx->wave_min_features));
+#ifdef PAGK_ALL_VARIANTS
         const bool use_mfma = !use_wave && mfma_ok && (ctx->kernel == 2 || (ctx->kernel == 0 && n_sel >= ctx->mfma_min_features));
+#else
+        const bool use_mfma = false;   // (variant (b) is not in this build)
+#endif
         ctx->last_variant = ctx->kernel == 1 ? 1 : use_levels ? 7 : use_rows ? 6 : (use_quad ? 5 : (use_wave ? 3 : ((ctx->kernel == 4 && mfma_ok) ? 4 : (use_mfma ? 2 : 0))));
         if (ctx->kernel == 1) {
             hipLaunchKernelGGL(k_track_thread, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
+#ifdef PAGK_ALL_VARIANTS
         } else if (use_rows) {
             const int nch = (Pm + 63) / 64;
             const int slot = a.half == 5 ? 0 : (a.half == 7 ? 1 : 2);
@@ -566,6 +575,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_rows<4>);
             else if (a.half == 10) e = launch(k_track_rows<7>);
             HIPCHK(ctx, e);
+#endif
         } else if (use_quad || use_levels) {
             // four features per wave (pagk_quad_kernel.h): whole features per wave, or -- LEVELS -- one pyramid level per
             // wave (pyramids x ceil(n / 4) waves)
@@ -753,6 +763,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = launch(k_track_block<1, 1, 4, false, true>);
             else if (a.half == 10) e = launch(k_track_block<2, 25, 4, false, true>);
             HIPCHK(ctx, e);
+#ifdef PAGK_ALL_VARIANTS
         } else if (use_mfma) {
             const size_t lds = track_mfma_lds_bytes(a.half);
             auto launch = [&](auto kern) -> hipError_t {
@@ -765,6 +776,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
             else if (a.half == 7) e = lean ? launch(k_track_block<2, 1, 2, true, false, true>) : launch(k_track_block<2, 1, 2, true>);    // P = 225
             else if (a.half == 10) e = lean ? launch(k_track_block<4, 25, 2, true, false, true>) : launch(k_track_block<4, 25, 2, true>);  // P = 441
             HIPCHK(ctx, e);
+#endif
         } else {
             const int P = (2 * a.half + 1) * (2 * a.half + 1);
             const int nr = (P + kBlock - 1) / kBlock, tail = P % 32;
@@ -1109,9 +1121,27 @@ int pagk_set_stream(pagk_ctx *ctx, void *hip_stream)
     return PAGK_OK;
 }
 
+// Variants (b) (2-wave workgroup, f64 MFMA chain) and (e) (four independent rows per wave + work queue) win at no launch
+// size any more ((b) since round 3's instruction diet of the 4-wave kernel, (e) only beyond 60000
+// features) and nothing selects them automatically: they are compiled with -DPAGK_ALL_VARIANTS only (tools/ and the
+// tests build that library when they want them), so the product's build and code object do not carry their fifteen
+// instantiations.
+int pagk_has_variant(int32_t which)
+{
+#ifdef PAGK_ALL_VARIANTS
+    return which >= 0 && which <= 7;
+#else
+    return which >= 0 && which <= 7 && which != 2 && which != 6;
+#endif
+}
+
 int pagk_set_kernel(pagk_ctx *ctx, int32_t which)
 {
     if (!ctx || which < 0 || which > 7) return PAGK_E_ARG;
+    if (!pagk_has_variant(which)) {
+        snprintf(ctx->err, sizeof(ctx->err), "variant %d is not in this build of libpagk_hip.so (compile with -DPAGK_ALL_VARIANTS)", which);
+        return PAGK_E_UNSUPPORTED;
+    }
     ctx->kernel = which;
     return PAGK_OK;
 }

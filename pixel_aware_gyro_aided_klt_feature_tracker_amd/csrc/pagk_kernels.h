@@ -1246,7 +1246,9 @@ __global__ void __launch_bounds__(256, 4) k_track_block_pyr(TrackArgs a, PyrArgs
 
 #include "pagk_wave_kernel.h"
 #include "pagk_quad_kernel.h"
+#ifdef PAGK_ALL_VARIANTS
 #include "pagk_rows_kernel.h"
+#endif
 #include "pagk_score_kernel.h"
 #include "pagk_neighbor_kernel.h"
 #include "pagk_selftest_kernel.h"

@@ -11,7 +11,7 @@ import torch
 from oracle import pagk_oracle as orc
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, distributed, runtime, synth
 
-from util import assert_parity, golden_cases, load_golden, params_for
+from util import assert_parity, built_variants, golden_cases, load_golden, needs_variant, params_for
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,7 @@ def test_thread_kernel_matches_golden_vectors(ctx, name):
     assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
 
 
+@needs_variant(2)
 @pytest.mark.parametrize("name", golden_cases())
 def test_mfma_kernel_matches_golden_vectors(ctx, name):
     # 2-wave workgroups, ordered accumulation as a v_mfma_f64_4x4x4f64 chain (sequential FMA over k)
@@ -59,6 +60,7 @@ def test_mfma_kernel_matches_golden_vectors(ctx, name):
     assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
 
 
+@needs_variant(2)
 @pytest.mark.parametrize("idx,n", [(1, 1000), (3, 6000)])
 def test_mfma_kernel_on_baseline_configs(ctx, idx, n):
     w = synth.config(idx, n=n)
@@ -107,6 +109,7 @@ def test_quad_kernel_on_baseline_configs(ctx, idx, n):
     assert_parity(got, ref, w.n, exact=True, what=w.name)
 
 
+@needs_variant(6)
 @pytest.mark.parametrize("name", golden_cases())
 def test_rows_kernel_matches_golden_vectors(ctx, name):
     # four independent rows per wave + work queue (pagk_rows_kernel.h)
@@ -120,6 +123,7 @@ def test_rows_kernel_matches_golden_vectors(ctx, name):
     assert_parity(got, exp, inp["pt_ref"].shape[0], exact=True, what=name)
 
 
+@needs_variant(6)
 @pytest.mark.parametrize("idx,n", [(1, 1000), (1, 1001), (1, 1002), (1, 1003), (3, 6000)])
 def test_rows_kernel_on_baseline_configs(ctx, idx, n):
     w = synth.config(idx, n=n)
@@ -156,12 +160,13 @@ def test_level_kernel_on_baseline_configs(ctx, idx, n):
 def test_quad_and_rows_kernels_with_fewer_features_than_rows(ctx, n):
     # a wave whose rows outnumber the features: spare rows shadow / idle and write nothing
     w = synth.config(1, n=n)
-    for kernel in (5, 6, 7):
+    for kernel in built_variants((5, 6, 7)):
         got, ref = run_both(ctx, params_for(w), w, kernel=kernel)
         assert_parity(got, ref, w.n, exact=True, what=f"kernel {kernel}, {n} features")
         assert ctx.last_variant() == kernel
 
 
+@needs_variant(6)
 @pytest.mark.parametrize("waves", [1, 3, 64])
 def test_rows_kernel_work_queue(monkeypatch, waves):
     # a grid of `waves` wavefronts: all but the first 4 * waves features reach their row through the queue, rows of a
@@ -399,7 +404,7 @@ def test_garbage_coordinates_are_safe_and_defined(ctx):
     p = params_for(w)
     with np.errstate(all="ignore"):
         ref = orc.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
-    for k in (0, 1, 2, 3, 5):
+    for k in built_variants((0, 1, 2, 3, 5)):
         ctx.set_kernel(k)
         try:
             got = ctx.track(p, w.img_ref, w.img_cur, pr, pi, A, w.status_in)
@@ -444,7 +449,7 @@ def test_odd_sized_images(ctx, width, height, L):
         lvl = orc.pyr_down(lvl)
         assert np.array_equal(ctx.frame_download_level(1, l, width, height), lvl), f"level {l}"
     p = params_for(w)
-    for kernel in (0, 2, 3):
+    for kernel in built_variants((0, 2, 3)):
         got, ref = run_both(ctx, p, w, kernel=kernel)
         assert_parity(got, ref, w.n, exact=True, what=f"{width}x{height} L={L} kernel {kernel}")
     assert ref["status"][:w.n].sum() > 150
@@ -947,7 +952,7 @@ def test_randomized_parity_sweep(ctx, seed):
     ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
     # auto, thread-per-feature, MFMA 2-wave, wave-per-feature, four features per wave, four rows + queue (the last
     # four fall back where a patch size is not built)
-    for kernel in (0, 1, 2, 3, 5, 6):
+    for kernel in built_variants((0, 1, 2, 3, 5, 6)):
         ctx.set_kernel(kernel)
         try:
             got = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from util import built_variants
+
 from oracle import pagk_oracle as orc
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, host_api, synth
 
@@ -131,7 +133,7 @@ def test_baseline_config2_shape_with_superpoint_keypoints(built):
     pu, pd, st, A = orc.gyro_predict(p, 640, 480, 10, KRK, Rp.astype(np.float32)[2], kp)
     ctx = capi.Context(0)
     try:
-        for kernel in (0, 2, 3):
+        for kernel in built_variants((0, 2, 3)):
             ctx.set_kernel(kernel)
             got = ctx.track(p, w.img_ref, w.img_cur, kp, pu, A, st)
             ref = orc.track(p, w.img_ref, w.img_cur, kp, pu, A, st, nthreads=16)

@@ -10,7 +10,7 @@ import pytest
 from oracle import pagk_oracle as orc
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
 
-from util import assert_parity, params_for
+from util import assert_parity, params_for, needs_variant
 
 pytestmark = pytest.mark.gpu
 
@@ -139,7 +139,7 @@ def test_variants_differ_where_the_readme_says_they_do(ctx):
         assert (_bits(np.nan_to_num(alt)) != _bits(np.nan_to_num(base))).any(), mask
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("kernel", [0, 1, pytest.param(2, marks=needs_variant(2)), 3, 5, pytest.param(6, marks=needs_variant(6))])
 @pytest.mark.parametrize("mask", [1, 8, 32, 1 | 2 | 4 | 8 | 32])
 def test_tracking_kernels_follow_solver_variant(ctx, alternatives, kernel, mask):
     """Every exact tracking variant with pagk_params::solver_variant = mask against the oracle with the same

@@ -32,6 +32,20 @@ def load_golden(name):
     return params, inputs, expected
 
 
+def built_variants(ks):
+    """The kernel variants of `ks` that the loaded library carries (2 and 6 need -DPAGK_ALL_VARIANTS: tools/build_all_variants.py)."""
+    return [k for k in ks if capi.has_variant(k)]
+
+
+def needs_variant(k):
+    import pytest
+    try:
+        missing = not capi.has_variant(k)
+    except Exception:   # (library not built yet: let the test itself say so)
+        missing = False
+    return pytest.mark.skipif(missing, reason=f"variant {k} is not in the product's build (PAGK_LIB=tools/bin/libpagk_hip_all.so runs it)")
+
+
 def params_for(w, **kw):
     return capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                             camera=w.camera, illumination=kw.get("illumination", True), affine=kw.get("affine", True),

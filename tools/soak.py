@@ -10,7 +10,8 @@ import test_parity_gpu as T
 from util import assert_parity
 first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 # PAGK_SOAK_KERNELS=0,2,3,5,6 (default); with PAGK_QUAD_BUDGET / PAGK_ROWS_WAVES set, the hand-over and the queue are soaked too
-KERNELS = tuple(int(k) for k in os.environ.get("PAGK_SOAK_KERNELS", "0,2,3,5,6").split(","))
+KERNELS = tuple(k for k in (int(v) for v in os.environ.get("PAGK_SOAK_KERNELS", "0,2,3,5,6,7").split(",")) if capi.has_variant(k))
+# (2 and 6 only in a -DPAGK_ALL_VARIANTS build: PAGK_LIB=tools/bin/libpagk_hip_all.so, tools/build_all_variants.py)
 ctx = capi.Context(0)
 bad = 0
 feats = 0
