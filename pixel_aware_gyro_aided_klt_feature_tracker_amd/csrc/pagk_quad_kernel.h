@@ -245,6 +245,10 @@ __global__ void __launch_bounds__(64, 4) k_track_quad(TrackArgs a)
             // address-dependent on the entry and a wave's loads return in order -- that dependency is the consumer's
             // ordering; do not index the state by the ticket)
             quad = __builtin_amdgcn_readfirstlane(e) - 1;
+#ifdef PAGK_EXPERIMENT_ACQUIRE_ONCE
+            // A/B build: ONE agent-scope acquire per wave, behind the look that found the entry -- not one per look
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         }
     }
     // LEVELS: this wave's quad is through with its level -- the next level's consumers may have it

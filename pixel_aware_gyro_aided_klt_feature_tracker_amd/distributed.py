@@ -75,9 +75,13 @@ class Gathered:
         # result into the same buffer can wait for this reader
         self.done = None
         self.consumed = None
+        self.stale = False   # set when a later step's gather has been issued into `raw` (runtime.GatherRing)
 
     def unpack(self) -> dict:
         """Full-length per-field tensors on the caller's current stream, ordered after the collective."""
+        if self.stale:
+            raise RuntimeError("this gathered result's buffer has been reused by a later step; unpack a result before "
+                               "the step after next is issued")
         if self.raw.is_cuda:
             cur = torch.cuda.current_stream(self.raw.device)
             if self.done is not None:

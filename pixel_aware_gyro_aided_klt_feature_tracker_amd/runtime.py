@@ -12,6 +12,45 @@ import torch
 from . import capi, distributed
 
 
+def _event_on(stream):
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+class GatherRing:
+    """The two alternating buffers of the sharded step's all-gather and the event ordering around them, apart from the
+    streams so that the ordering can be tested without a GPU (tests/test_distributed_cpu.py).  The result of step k stays
+    intact while step k+1's gather runs; the gather of step k+2 goes into step k's buffer: it waits for whoever unpacked
+    that result (Gathered.consumed), and the old result is marked stale -- unpack() of a stale result raises instead of
+    returning a later step's bytes.  `new_event(stream)` returns an event recorded on `stream`."""
+
+    def __init__(self, new_event):
+        self.bufs = [None, None]
+        self.prev = [None, None]
+        self.turn = 0
+        self.new_event = new_event
+
+    def issue(self, side, tracked, gather):
+        """Order `gather(out_buffer)` on `side` behind `tracked` (the tracking launch that filled the local slice) and
+        behind the reader of the buffer it is about to overwrite.  Returns (result, event: the collective is done)."""
+        k = self.turn
+        self.turn = 1 - k
+        side.wait_event(tracked)
+        prev = self.prev[k]
+        if prev is not None:
+            if prev.consumed is not None:
+                side.wait_event(prev.consumed)
+            prev.stale = True
+        res = gather(self.bufs[k])
+        done = self.new_event(side)
+        if isinstance(res, distributed.Gathered):
+            self.bufs[k] = res.raw
+            res.done = done              # unpack() / to_numpy() on any stream wait for the collective
+            self.prev[k] = res
+        return res, done
+
+
 class ResidentTracker:
     """One frame pair resident in HBM; step() = what a tracker does per new frame:
     build the pyramid of the new (current) frame, then run PatchMatch over this rank's
@@ -236,28 +275,11 @@ class ResidentTracker:
                 self.mode_used = "serial"
             tracked = torch.cuda.Event()
             tracked.record(self.main)
-        # Two gather buffers, alternating: the result of step k stays intact while step k+1's gather runs, and a gather
-        # into a buffer waits for whoever unpacked the result that lived there (Gathered.consumed).
-        bufs = getattr(self, "_gather_bufs", None)
-        if bufs is None:
-            bufs = self._gather_bufs = [None, None]
-            self._gather_prev = [None, None]
-            self._gather_turn = 0
-        k = self._gather_turn
-        self._gather_turn = 1 - k
+        ring = getattr(self, "_gather_ring", None)
+        if ring is None:
+            ring = self._gather_ring = GatherRing(_event_on)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(tracked)
-            prev = self._gather_prev[k]
-            if prev is not None and prev.consumed is not None:
-                self.side.wait_event(prev.consumed)
-            res = distributed.all_gather_results(self.out, self.n, out=bufs[k])
-            done = torch.cuda.Event()
-            done.record(self.side)
-            self._gather_done = done
-            if isinstance(res, distributed.Gathered):
-                bufs[k] = res.raw
-                res.done = done          # unpack() / to_numpy() on any stream wait for the collective
-                self._gather_prev[k] = res
+            res, self._gather_done = ring.issue(self.side, tracked, lambda out: distributed.all_gather_results(self.out, self.n, out=out))
         self._last_gather = res
         return res
 
@@ -302,7 +324,7 @@ class ResidentTracker:
             for _ in range(reps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.side)
-                distributed.all_gather_results(self.out, self.n, out=(getattr(self, "_gather_bufs", None) or [None])[0])
+                distributed.all_gather_results(self.out, self.n, out=(self._gather_ring.bufs[0] if getattr(self, "_gather_ring", None) else None))
                 e1.record(self.side)
                 e1.synchronize()
                 ts.append(e0.elapsed_time(e1))

@@ -100,3 +100,59 @@ def test_group_creation_fails_loudly_without_a_device(built):
     with pytest.raises(capi.PagkError) as e:
         capi.Multi([0])
     assert e.value.code == capi.PAGK_E_NODEVICE
+
+
+def test_gather_ring_orders_two_alternating_buffers(built):
+    """the event ordering of the sharded step's two gather buffers, with stand-ins for the streams and the
+    collective (runtime.GatherRing is the code ResidentTracker._sharded_step runs; no GPU needed): a gather into a buffer
+    comes after the tracking launch of its step and after the reader of the result that lived in that buffer, the result
+    of step k survives step k + 1, and a result whose buffer has been handed to a later gather refuses to unpack."""
+    from pixel_aware_gyro_aided_klt_feature_tracker_amd import distributed, runtime
+
+    log = []
+
+    class Stream:
+        def wait_event(self, ev):
+            log.append(("wait", ev))
+
+    issued = []
+
+    def new_event(stream):
+        ev = "done%d" % len(issued)
+        log.append(("record", ev))
+        return ev
+
+    m = 5
+    nbytes = distributed.alloc_device_outputs(m, "cpu")["_buf"].numel()
+
+    def gather(out):
+        raw = out if out is not None else torch.zeros(2 * nbytes, dtype=torch.uint8)
+        raw.fill_(len(issued) + 1)                         # (the collective writes the buffer)
+        log.append(("gather", raw.data_ptr()))
+        issued.append(distributed.Gathered(raw, 2, m, 2 * m - 1, nbytes))
+        return issued[-1]
+
+    ring, side = runtime.GatherRing(new_event), Stream()
+    r0, d0 = ring.issue(side, "tracked0", gather)
+    assert log == [("wait", "tracked0"), ("gather", r0.raw.data_ptr()), ("record", "done1")] and r0.done == d0 == "done1"
+    r0.consumed = "read0"                                  # (what unpack() records on a device result)
+    del log[:]
+    r1, d1 = ring.issue(side, "tracked1", gather)
+    assert r1.raw.data_ptr() != r0.raw.data_ptr(), "step 1 must not overwrite the result of step 0"
+    assert log == [("wait", "tracked1"), ("gather", r1.raw.data_ptr()), ("record", "done2")] and not r0.stale
+    assert int(r0.raw[0]) == 1 and set(r0.unpack()) == {name for name, _, _ in distributed.FIELDS}
+    del log[:]
+    r2, d2 = ring.issue(side, "tracked2", gather)          # back in buffer 0: behind step 0's reader
+    assert r2.raw.data_ptr() == r0.raw.data_ptr()
+    assert log == [("wait", "tracked2"), ("wait", "read0"), ("gather", r2.raw.data_ptr()), ("record", "done3")]
+    assert r0.stale and not r1.stale and not r2.stale
+    with pytest.raises(RuntimeError, match="reused"):
+        r0.unpack()
+    del log[:]
+    r3, _ = ring.issue(side, "tracked3", gather)           # buffer 1; step 1's result was never unpacked: nobody to wait for
+    assert r3.raw.data_ptr() == r1.raw.data_ptr() and r1.stale
+    assert log == [("wait", "tracked3"), ("gather", r3.raw.data_ptr()), ("record", "done4")]
+    # a single-rank step returns the local views, not a Gathered: the ring keeps nothing of it
+    plain = runtime.GatherRing(new_event)
+    res, _ = plain.issue(side, "t", lambda out: {"status": None})  # (world 1: all_gather_results returns the local views)
+    assert res == {"status": None} and plain.prev == [None, None] and plain.bufs == [None, None]
