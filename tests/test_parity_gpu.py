@@ -306,6 +306,43 @@ def test_level_kernel_reports_a_wait_that_ran_out(monkeypatch):
         c.close()
 
 
+def test_a_failed_level_launch_leaves_nothing_stale_for_a_caller_on_its_own_stream(ctx, monkeypatch):
+    """a caller that synchronises its own stream never passes through pagk_sync.  It must (a) learn
+    of the failure from pagk_check_launch (ResidentTracker.synchronize calls it) and (b) never find the previous frame's
+    outputs where this launch tracked nothing: a wave that gives up clears the launch's status array, so afterwards a
+    feature either has status 0 or carries this launch's genuine result."""
+    w = synth.config(1, n=6000)
+    p = params_for(w)
+    good = ctx.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+    monkeypatch.setenv("PAGK_LEVEL_POLLS", "0")
+    rt = runtime.ResidentTracker(p, device=0)
+    try:
+        rt.ctx.set_kernel(7)
+        rt.load_pair(w.img_ref, w.img_cur)
+        rt.set_features(w.pt_ref, w.pt_init, w.affine, w.status_in)
+        failed = False
+        for _ in range(3):
+            rt.out["status"].fill_(1)              # what a previous frame would have left behind
+            rt.out["pt_un"].fill_(-777.0)
+            torch.cuda.synchronize()
+            rt.step(mode="serial")
+            try:
+                rt.synchronize()
+            except capi.PagkError:
+                failed = True
+                break
+        assert failed, "no wave gave up although every wait was limited to one look"
+        rt.ctx.check_launch()                      # (reported once; the flag is cleared)
+        st = rt.out["status"][:w.n].cpu().numpy()
+        pt = rt.out["pt_un"][:w.n].cpu().numpy()
+        tracked = st != 0
+        assert (good["status"][:w.n] != 0).sum() > tracked.sum(), "the failed launch claims as many features as a good one"
+        assert np.array_equal(pt[tracked], good["pt_un"][:w.n][tracked]), "a feature with status 1 carries something else than its result"
+        assert not np.any(pt[tracked] == -777.0)
+    finally:
+        rt.close()
+
+
 @pytest.mark.parametrize("idx,n", [(0, 500), (1, 1000), (2, 2000), (3, 3000)])
 def test_baseline_configs_against_oracle(ctx, idx, n):
     # BASELINE.json configs (synthetic stand-ins, SURVEY.md §8(d)); 21x21 patch, 30 iterations
