@@ -181,8 +181,11 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
  * of variant 7 whose four-feature groups carry their stream; smaller batches, calculate_ncc and one-level pyramids run
  * as k launches.  The launch is issued on ctxs[0]'s stream: it waits for what the other contexts' streams have enqueued
  * so far, and their later work waits for it (contexts switched to one common stream with pagk_set_stream need neither,
- * and can be captured together: pagk_graph_begin(ctxs[0]) ... pagk_graph_end).  Pointer arrays are host arrays of device
- * pointers; d_pt_init_un / d_affine may be NULL when the flags do not use them.  k <= 64, all contexts on one device. */
+ * and can be captured together: pagk_graph_begin(ctxs[0]) ... pagk_graph_end -- after the same call has been issued once
+ * directly, at most two batched calls per capture: the stream descriptors a captured launch reads are buffers that
+ * pagk_graph_begin reserves and the graph owns, so that no later call can rewrite them under a replay; a direct call's are
+ * not reused before that launch is over).  Pointer arrays are host arrays of device pointers, read during the call;
+ * d_pt_init_un / d_affine may be NULL when the flags do not use them.  k <= 64, all contexts on one device. */
 int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params *params, const int32_t *slot_ref,
                             const int32_t *slot_cur, const int32_t *n, const float *const *d_pt_ref_un,
                             const float *const *d_pt_init_un, const float *const *d_affine,

@@ -58,8 +58,22 @@ struct pagk_ctx {
     int *susp_count_dev = nullptr;  // the hand-over count of the last launch that used one (in `susp` or in `lv`)
     void *lv = nullptr;       // one-level-per-wave launches: 8 sequences' counters (8 x 4096 B) | ready lists | float state[4 n]
     size_t lv_bytes = 0;
-    void *batch_dev = nullptr, *batch_host = nullptr;  // pagk_track_device_batch (lead context): the BatchStream array and its pinned mirror
-    int batch_cap = 0;
+    // pagk_track_device_batch (lead context): the BatchStream array of a launch and its pinned source.  The copy to the
+    // device is asynchronous, and a captured copy is replayed long after the call: a pair is therefore never rewritten
+    // while something may still read it.  Direct launches take the pairs of a ring in turn (a pair is reused four calls
+    // later, after waiting for the launch that used it); a capture takes pairs that pagk_graph_begin reserved for it and
+    // that belong to the graph from then on (freed by pagk_graph_destroy).  Every pair holds the maximum of 64 streams.
+    struct BatchDesc {
+        void *host = nullptr, *dev = nullptr;
+        hipEvent_t used = nullptr;   // recorded behind the launch that read `dev`
+        bool recorded = false;
+    };
+    static constexpr int kBatchRing = 4, kBatchPerCapture = 2, kBatchMaxStreams = 64;
+    BatchDesc batch_ring[kBatchRing];
+    int batch_turn = 0;
+    bool batch_seen = false;                 // this context has led a batched launch: captures reserve pairs
+    std::vector<BatchDesc> cap_batch;        // reserved for the running capture
+    int cap_batch_used = 0;
     hipEvent_t ev_batch = nullptr;  // orders a batched launch against the streams of the contexts it serves
     int *lv_error = nullptr;  // mapped host memory: a wave of such a launch gave up waiting (never expected; checked at syncs)
     int *lv_error_dev = nullptr;  // ... as the device addresses it
@@ -94,6 +108,7 @@ struct pagk_ctx {
         size_t lds = 0;
     };
     std::vector<GraphSeg> pre_segs[kGraphs];
+    std::vector<BatchDesc> graph_batch[kGraphs];   // the descriptor pairs graph k's batched launches read
     std::vector<GraphSeg> cap_segs;   // segments closed so far in the capture that is open
     hipEvent_t ev_trk[2] = {}, ev_pyr[2] = {};
     bool trk_timed = false, pyr_timed = false;
@@ -196,6 +211,28 @@ void destroy_segs(std::vector<pagk_ctx::GraphSeg> &v)
         if (sg.ex) (void)hipGraphExecDestroy(sg.ex);
         if (sg.g) (void)hipGraphDestroy(sg.g);
     }
+    v.clear();
+}
+
+int batch_desc_alloc(pagk_ctx *ctx, pagk_ctx::BatchDesc &d)
+{
+    const size_t bytes = (size_t)pagk_ctx::kBatchMaxStreams * sizeof(BatchStream);
+    HIPCHK(ctx, hipMalloc(&d.dev, bytes));
+    HIPCHK(ctx, hipHostMalloc(&d.host, bytes, hipHostMallocDefault));
+    HIPCHK(ctx, hipEventCreateWithFlags(&d.used, hipEventDisableTiming));
+    d.recorded = false;
+    return PAGK_OK;
+}
+void batch_desc_free(pagk_ctx::BatchDesc &d)
+{
+    if (d.dev) (void)hipFree(d.dev);
+    if (d.host) (void)hipHostFree(d.host);
+    if (d.used) (void)hipEventDestroy(d.used);
+    d = pagk_ctx::BatchDesc();
+}
+void batch_desc_free(std::vector<pagk_ctx::BatchDesc> &v)
+{
+    for (auto &d : v) batch_desc_free(d);
     v.clear();
 }
 
@@ -1102,8 +1139,9 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->susp) (void)hipFree(ctx->susp);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->lv) (void)hipFree(ctx->lv);
-    if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
-    if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
+    for (auto &d : ctx->batch_ring) batch_desc_free(d);
+    batch_desc_free(ctx->cap_batch);
+    for (int k = 0; k < pagk_ctx::kGraphs; k++) batch_desc_free(ctx->graph_batch[k]);
     if (ctx->ev_batch) (void)hipEventDestroy(ctx->ev_batch);
     if (ctx->lv_error) (void)hipHostFree(ctx->lv_error);
     for (int k = 0; k < 2; k++) {
@@ -1356,21 +1394,31 @@ int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params 
     fill_param_args(a, params);
     a.n = 4 * total_q;   // features numbered through the batch, each stream padded to whole quads
     a.batch_k = k;
-    // the stream descriptors: pinned mirror -> device (inside a capture the copy is a node of the graph)
-    if (k > lead->batch_cap) {
-        if (in_capture(lead)) {
-            snprintf(lead->err, sizeof(lead->err), "the batch descriptors would have to be (re)allocated during graph capture");
+    // the stream descriptors: pinned source -> device.  The copy is asynchronous and, inside a capture, a node that is
+    // replayed later: the pair it uses is this launch's alone until the launch is over (ring) / the graph's (capture)
+    pagk_ctx::BatchDesc *desc = nullptr;
+    if (in_capture(lead)) {
+        if (!lead->capturing || lead->cap_batch_used >= (int)lead->cap_batch.size()) {
+            snprintf(lead->err, sizeof(lead->err), "a batched launch inside a graph capture needs descriptor buffers reserved by pagk_graph_begin of "
+                     "ctxs[0]: issue the batched call once before capturing, capture through pagk_graph_begin(ctxs[0]), at most %d batched calls per capture",
+                     pagk_ctx::kBatchPerCapture);
             return PAGK_E_ARG;
         }
-        if (int gr = no_live_graphs(lead, "the batch descriptors")) return gr;
-        if (lead->batch_dev) HIPCHK(lead, hipFree(lead->batch_dev));
-        if (lead->batch_host) HIPCHK(lead, hipHostFree(lead->batch_host));
-        lead->batch_dev = lead->batch_host = nullptr, lead->batch_cap = 0;
-        HIPCHK(lead, hipMalloc(&lead->batch_dev, (size_t)k * sizeof(BatchStream)));
-        HIPCHK(lead, hipHostMalloc(&lead->batch_host, (size_t)k * sizeof(BatchStream), hipHostMallocDefault));
-        lead->batch_cap = k;
+        desc = &lead->cap_batch[lead->cap_batch_used++];
+    } else {
+        desc = &lead->batch_ring[lead->batch_turn];
+        lead->batch_turn = (lead->batch_turn + 1) % pagk_ctx::kBatchRing;
+        if (!desc->dev) {
+            if (int ar = batch_desc_alloc(lead, *desc)) {
+                batch_desc_free(*desc);
+                return ar;
+            }
+        } else if (desc->recorded) {
+            HIPCHK(lead, hipEventSynchronize(desc->used));   // (the launch four calls ago)
+        }
+        lead->batch_seen = true;
     }
-    BatchStream *hb = static_cast<BatchStream *>(lead->batch_host);
+    BatchStream *hb = static_cast<BatchStream *>(desc->host);
     int qb = 0;
     for (int j = 0; j < k; j++) {
         pagk_ctx *c = ctxs[j];
@@ -1396,8 +1444,8 @@ int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params 
             HIPCHK(lead, hipEventRecord(ctxs[j]->ev_batch, ctxs[j]->stream));
             HIPCHK(lead, hipStreamWaitEvent(lead->stream, ctxs[j]->ev_batch, 0));
         }
-    HIPCHK(lead, hipMemcpyAsync(lead->batch_dev, hb, (size_t)k * sizeof(BatchStream), hipMemcpyHostToDevice, lead->stream));
-    a.batch = static_cast<const BatchStream *>(lead->batch_dev);
+    HIPCHK(lead, hipMemcpyAsync(desc->dev, hb, (size_t)k * sizeof(BatchStream), hipMemcpyHostToDevice, lead->stream));
+    a.batch = static_cast<const BatchStream *>(desc->dev);
     // workspaces of a one-level-per-wave launch (launch_track), for the batch's quads; no hand-over
     const int Pm = (2 * a.half + 1) * (2 * a.half + 1), nch = (Pm + 63) / 64, nq = total_q, waves = nq * params->pyramids;
     const size_t need = (size_t)waves * 4 * nch * 64 * sizeof(float);
@@ -1443,6 +1491,10 @@ int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params 
     else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true, true>) : launch(k_track_quad<4, false, true, true>);
     else e = lean ? launch(k_track_quad<7, true, true, true>) : launch(k_track_quad<7, false, true, true>);
     HIPCHK(lead, e);
+    if (!in_capture(lead)) {
+        HIPCHK(lead, hipEventRecord(desc->used, lead->stream));
+        desc->recorded = true;
+    }
     if (lead->ev_trk[1] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_trk[1], lead->stream));
     if (!in_capture(lead)) lead->trk_timed = true;
     // ... and whatever those streams do next sees its results
@@ -1696,6 +1748,16 @@ int pagk_graph_begin(pagk_ctx *ctx)
     if (!ctx || ctx->capturing) return PAGK_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     destroy_segs(ctx->cap_segs);
+    batch_desc_free(ctx->cap_batch);
+    ctx->cap_batch_used = 0;
+    if (ctx->batch_seen) {   // a context that leads batched launches: the capture's own descriptor pairs (no allocation inside a capture)
+        ctx->cap_batch.resize(pagk_ctx::kBatchPerCapture);
+        for (auto &d : ctx->cap_batch)
+            if (int ar = batch_desc_alloc(ctx, d)) {
+                batch_desc_free(ctx->cap_batch);
+                return ar;
+            }
+    }
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
     return PAGK_OK;
@@ -1716,6 +1778,7 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
     if (id < 0 || !g) {
         if (g) (void)hipGraphDestroy(g);
         destroy_segs(ctx->cap_segs);
+        batch_desc_free(ctx->cap_batch);
         snprintf(ctx->err, sizeof(ctx->err), id < 0 ? "all %d graph slots are in use" : "capture produced no graph (%d)", pagk_ctx::kGraphs);
         return PAGK_E_ARG;
     }
@@ -1724,6 +1787,7 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g);
         destroy_segs(ctx->cap_segs);
+        batch_desc_free(ctx->cap_batch);
         snprintf(ctx->err, sizeof(ctx->err), "hipGraphInstantiate -> %s", hipGetErrorString(e));
         return PAGK_E_HIP;
     }
@@ -1731,6 +1795,10 @@ int pagk_graph_end(pagk_ctx *ctx, int32_t *graph_id)
     ctx->graph_execs[id] = ex;
     ctx->pre_segs[id] = std::move(ctx->cap_segs);   // (empty for a capture without a live finisher: one graph, as before)
     ctx->cap_segs.clear();
+    batch_desc_free(ctx->graph_batch[id]);
+    ctx->graph_batch[id] = std::move(ctx->cap_batch);   // (unused reserved pairs go with it: freed with the graph)
+    ctx->cap_batch.clear();
+    ctx->cap_batch_used = 0;
     *graph_id = id;
     return PAGK_OK;
 }
@@ -1764,6 +1832,7 @@ int pagk_graph_destroy(pagk_ctx *ctx, int32_t graph_id)
     (void)hipGraphExecDestroy(ctx->graph_execs[graph_id]);
     (void)hipGraphDestroy(ctx->graphs[graph_id]);
     destroy_segs(ctx->pre_segs[graph_id]);
+    batch_desc_free(ctx->graph_batch[graph_id]);
     ctx->graph_execs[graph_id] = nullptr;
     ctx->graphs[graph_id] = nullptr;
     return lv_check(ctx);
