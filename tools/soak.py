@@ -17,6 +17,17 @@ bad = 0
 feats = 0
 for seed in range(first, first + count):
     w, flags = T._random_case(seed)
+    if os.environ.get("PAGK_SOAK_CROWDED"):
+        # the pipelined 4-wave body (h = 8 / 9 / 10) with every CU holding several workgroups: its LDS flag protocol under
+        # contention, all flag combinations (LEAN and generic instantiations), 1-4 levels
+        rng = np.random.default_rng(seed ^ 0x5EED)
+        L = int(rng.integers(1, 5))
+        mult = 1 << (L - 1)
+        w = T.synth.make_workload("crowd", mult * int(rng.integers(40, 160)), mult * int(rng.integers(30, 120)),
+                                  int(rng.integers(800, 3500)), seed=seed, half_patch=int(rng.integers(8, 11)),
+                                  iterations=int(rng.integers(2, 31)), pyramids=L, motion="rotation", has_gyro=True,
+                                  omega=tuple(rng.uniform(-1.0, 1.0, 3)), edge_fraction=float(rng.choice([0.0, 0.3])),
+                                  gain=float(rng.uniform(0.8, 1.25)), offset=float(rng.uniform(-10, 10)))
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro,
                          camera=w.camera, **flags)
     ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=8)
