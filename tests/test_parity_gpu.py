@@ -828,6 +828,49 @@ def test_batch_descriptors_of_one_call_are_never_rewritten_by_another(ctx):
         cb.close()
 
 
+def test_batched_launch_refuses_what_it_cannot_do(ctx):
+    """Error behaviour of pagk_track_device_batch (include/pagk.h): argument errors are PAGK_E_ARG, never a launch; a
+    batched launch inside a capture needs the descriptor buffers pagk_graph_begin reserves for a context that has led
+    a batch before -- a first batched call INSIDE a capture is refused with a message that says what to do."""
+    ws = _ragged_streams()[:2]
+    p = params_for(ws[0][0])
+    cb = runtime.CameraBatch(p, len(ws), device=0)
+    try:
+        for j, (w, n) in enumerate(ws):
+            cb.load(j, w.img_ref, w.img_cur, w.pt_ref[:n], w.pt_init[:n], w.affine[:n], w.status_in[:n])
+        cams = cb.cams
+        cams[0].ctx.set_kernel(7)
+
+        def call(ctxs=None, slots_cur=None, ns=None):
+            cs = cams if ctxs is None else ctxs
+            k = len(cs)
+            capi.Context.track_device_batch([c.ctx for c in cs], p, [0] * k, slots_cur or [1] * k,
+                                            ns or [c.hi - c.lo for c in cs], [c.d_pt_ref for c in cs],
+                                            [c.d_pt_init for c in cs], [c.d_affine for c in cs], [c.d_status for c in cs],
+                                            [c.out for c in cs])
+
+        for bad in (dict(ctxs=cams * 33), dict(slots_cur=[1, 7]), dict(slots_cur=[1, 3]), dict(ns=[-1, 5])):   # 66 streams; no such slot; empty slot; n < 0
+            with pytest.raises(capi.PagkError) as ei:
+                call(**bad)
+            assert ei.value.code == capi.PAGK_E_ARG, bad
+        with torch.cuda.stream(cb.stream):
+            cams[0].ctx.graph_begin()                     # this context has never led a batch: nothing reserved
+            try:
+                cams[0].rebuild_current_pyramid(1)        # (something capturable, so that the capture is not empty)
+                with pytest.raises(capi.PagkError, match="once before capturing") as ei:
+                    call()
+                assert ei.value.code == capi.PAGK_E_ARG
+            finally:
+                gid = cams[0].ctx.graph_end()
+            cams[0].ctx.graph_destroy(gid)
+            call()                                        # the direct call works, and after it the capture does
+            cb.step(mode="graph")
+        cb.synchronize()
+        assert cb.mode_used == "graph"
+    finally:
+        cb.close()
+
+
 def test_small_batches_and_ncc_batches_run_as_their_own_launches(ctx):
     """Below the level kernel's threshold (and with calculate_ncc, which that kernel does not compute) a batch is k
     launches on the streams' own contexts: same entry point, same results."""
