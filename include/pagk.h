@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 301 /* 0.3.1: pipelined 4-wave kernel, pagk_track_device_batch, pagk_check_launch, pagk_selftest_repeat_sum */
+#define PAGK_VERSION 302 /* 0.3.2: + pagk_frame_set_device_batch; 0.3.1: pipelined 4-wave kernel, pagk_track_device_batch, pagk_check_launch, pagk_selftest_repeat_sum */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -151,6 +151,16 @@ int pagk_frame_upload_pinned(pagk_ctx *ctx, int32_t slot, const pagk_image *img,
  * rows of `step` bytes). Asynchronous on the context stream. */
 int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32_t width,
                           int32_t height, int64_t step, int32_t pyramids);
+/* pagk_frame_set_device for the frames of k contexts that share one device, as ONE launch: PatchMatch::CreatePyramids
+ * (src/patch_match.cpp:61-76) of k trackers that are stepped together (BASELINE configs[4], "batched multi-camera ...
+ * shared pyramid upload"); the producer side of pagk_track_device_batch.  Frame j (device image d_data[j], width[j] x
+ * height[j], rows step[j] bytes apart) goes into slot[j] of ctxs[j]; per frame the same bytes as pagk_frame_set_device.
+ * The launch is issued on ctxs[0]'s stream and ordered against the other contexts' streams like pagk_track_device_batch;
+ * its frame descriptors follow the same rules inside a capture (issue the call once directly first; at most four batched
+ * calls of either kind per capture).  Frames the single-launch kernel does not serve (a parent level with an odd
+ * dimension, more than four levels) make the call k per-context launches.  k <= 64. */
+int pagk_frame_set_device_batch(pagk_ctx *const *ctxs, int32_t k, const int32_t *slot, const void *const *d_data,
+                                const int32_t *width, const int32_t *height, const int64_t *step, int32_t pyramids);
 /* Copy one pyramid level of a slot back to the host (tests: pyramid parity). */
 int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst,
                               int32_t *width, int32_t *height);
@@ -182,7 +192,7 @@ int pagk_track_device_fused(pagk_ctx *ctx, const pagk_params *params, int32_t sl
  * as k launches.  The launch is issued on ctxs[0]'s stream: it waits for what the other contexts' streams have enqueued
  * so far, and their later work waits for it (contexts switched to one common stream with pagk_set_stream need neither,
  * and can be captured together: pagk_graph_begin(ctxs[0]) ... pagk_graph_end -- after the same call has been issued once
- * directly, at most two batched calls per capture: the stream descriptors a captured launch reads are buffers that
+ * directly, at most four batched calls (of this kind and of pagk_frame_set_device_batch together) per capture: the stream descriptors a captured launch reads are buffers that
  * pagk_graph_begin reserves and the graph owns, so that no later call can rewrite them under a replay; a direct call's are
  * not reused before that launch is over).  Pointer arrays are host arrays of device pointers, read during the call;
  * d_pt_init_un / d_affine may be NULL when the flags do not use them.  k <= 64, all contexts on one device. */

@@ -154,6 +154,9 @@ def declare(lib) -> None:
     lib.pagk_frame_download_level.argtypes = [vp, i32, i32, vp, _P(i32), _P(i32)]
     lib.pagk_track_device.restype = C.c_int
     lib.pagk_track_device.argtypes = [vp, _P(Params), i32, i32, i32, vp, vp, vp, vp, _P(Outputs)]
+    if hasattr(lib, "pagk_frame_set_device_batch"):
+        lib.pagk_frame_set_device_batch.restype = C.c_int
+        lib.pagk_frame_set_device_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32]
     if hasattr(lib, "pagk_track_device_batch"):
         lib.pagk_track_device_batch.restype = C.c_int
         lib.pagk_track_device_batch.argtypes = [vp, i32, _P(Params), vp, vp, vp, vp, vp, vp, vp, vp]
@@ -261,7 +264,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
-    "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch",
+    "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch", "pagk_frame_set_device_batch",
     "pagk_multi_comm_count", "pagk_has_variant",
 ]
 
@@ -377,6 +380,19 @@ class Context:
         self._check(self.lib.pagk_track_device(self.h, C.byref(params), slot_ref, slot_cur, n, _ptr(d_pt_ref),
                                                _ptr(d_pt_init), _ptr(d_affine), _ptr(d_status), C.byref(o)),
                     "pagk_track_device")
+
+    @staticmethod
+    def frame_set_device_batch(ctxs, slots, d_ptrs, widths, heights, steps, pyramids: int):
+        """pagk_frame_set_device_batch: the pyramids of k contexts' frames (device images) as ONE launch on ctxs[0]'s
+        stream; per frame the same bytes as frame_set_device."""
+        k = len(ctxs)
+        lib = ctxs[0].lib
+        hs = (C.c_void_p * k)(*[c.h for c in ctxs])
+        sl = (C.c_int32 * k)(*slots)
+        pp = (C.c_void_p * k)(*[int(p) for p in d_ptrs])
+        ww, hh = (C.c_int32 * k)(*widths), (C.c_int32 * k)(*heights)
+        st = (C.c_int64 * k)(*steps)
+        ctxs[0]._check(lib.pagk_frame_set_device_batch(hs, k, sl, pp, ww, hh, st, pyramids), "pagk_frame_set_device_batch")
 
     @staticmethod
     def track_device_batch(ctxs, params: Params, slots_ref, slots_cur, ns, d_pt_ref, d_pt_init, d_affine, d_status, d_outs):

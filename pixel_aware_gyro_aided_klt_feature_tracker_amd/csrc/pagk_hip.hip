@@ -60,7 +60,7 @@ struct pagk_ctx {
     size_t lv_bytes = 0;
     // pagk_track_device_batch (lead context): the BatchStream array of a launch and its pinned source.  The copy to the
     // device is asynchronous, and a captured copy is replayed long after the call: a pair is therefore never rewritten
-    // while something may still read it.  Direct launches take the pairs of a ring in turn (a pair is reused four calls
+    // while something may still read it.  Direct launches take the pairs of a ring in turn (a pair is reused six calls
     // later, after waiting for the launch that used it); a capture takes pairs that pagk_graph_begin reserved for it and
     // that belong to the graph from then on (freed by pagk_graph_destroy).  Every pair holds the maximum of 64 streams.
     struct BatchDesc {
@@ -68,7 +68,7 @@ struct pagk_ctx {
         hipEvent_t used = nullptr;   // recorded behind the launch that read `dev`
         bool recorded = false;
     };
-    static constexpr int kBatchRing = 4, kBatchPerCapture = 2, kBatchMaxStreams = 64;
+    static constexpr int kBatchRing = 6, kBatchPerCapture = 4, kBatchMaxStreams = 64;
     BatchDesc batch_ring[kBatchRing];
     int batch_turn = 0;
     bool batch_seen = false;                 // this context has led a batched launch: captures reserve pairs
@@ -216,6 +216,8 @@ void destroy_segs(std::vector<pagk_ctx::GraphSeg> &v)
 
 int batch_desc_alloc(pagk_ctx *ctx, pagk_ctx::BatchDesc &d)
 {
+    // (one size for both users: the BatchStream array of a tracking launch, the PyrBatchEntry array of a pyramid launch)
+    static_assert(sizeof(PyrBatchEntry) <= sizeof(BatchStream), "a descriptor pair is sized by the larger record");
     const size_t bytes = (size_t)pagk_ctx::kBatchMaxStreams * sizeof(BatchStream);
     HIPCHK(ctx, hipMalloc(&d.dev, bytes));
     HIPCHK(ctx, hipHostMalloc(&d.host, bytes, hipHostMallocDefault));
@@ -234,6 +236,47 @@ void batch_desc_free(std::vector<pagk_ctx::BatchDesc> &v)
 {
     for (auto &d : v) batch_desc_free(d);
     v.clear();
+}
+
+// The descriptor pair of the batched launch `lead` is about to issue: the next of the ring (after waiting for the launch
+// that used it last), or -- inside lead's own capture -- the next of those pagk_graph_begin reserved.  nullptr: *rc, lead->err.
+pagk_ctx::BatchDesc *batch_desc_take(pagk_ctx *lead, int *rc)
+{
+    *rc = PAGK_OK;
+    if (in_capture(lead)) {
+        if (!lead->capturing || lead->cap_batch_used >= (int)lead->cap_batch.size()) {
+            snprintf(lead->err, sizeof(lead->err), "a batched launch inside a graph capture needs descriptor buffers reserved by pagk_graph_begin of "
+                     "ctxs[0]: issue the batched call once before capturing, capture through pagk_graph_begin(ctxs[0]), at most %d batched calls per capture",
+                     pagk_ctx::kBatchPerCapture);
+            *rc = PAGK_E_ARG;
+            return nullptr;
+        }
+        return &lead->cap_batch[lead->cap_batch_used++];
+    }
+    pagk_ctx::BatchDesc *desc = &lead->batch_ring[lead->batch_turn];
+    lead->batch_turn = (lead->batch_turn + 1) % pagk_ctx::kBatchRing;
+    if (!desc->dev) {
+        if ((*rc = batch_desc_alloc(lead, *desc)) != PAGK_OK) {
+            batch_desc_free(*desc);
+            return nullptr;
+        }
+    } else if (desc->recorded) {
+        if (hipEventSynchronize(desc->used) != hipSuccess) {   // (the launch a ring's length ago)
+            snprintf(lead->err, sizeof(lead->err), "hipEventSynchronize of a batch descriptor's last user failed");
+            *rc = PAGK_E_HIP;
+            return nullptr;
+        }
+    }
+    lead->batch_seen = true;
+    return desc;
+}
+// ... and behind that launch: from here on the pair is busy until the launch is over
+int batch_desc_used(pagk_ctx *lead, pagk_ctx::BatchDesc *desc)
+{
+    if (in_capture(lead)) return PAGK_OK;   // (the graph owns it)
+    HIPCHK(lead, hipEventRecord(desc->used, lead->stream));
+    desc->recorded = true;
+    return PAGK_OK;
 }
 
 int slot_reserve(pagk_ctx *ctx, FrameSlot &s, int w, int h, int L)
@@ -1300,6 +1343,95 @@ int pagk_frame_set_device(pagk_ctx *ctx, int32_t slot, const void *d_data, int32
     return rc;
 }
 
+// pagk_frame_set_device for the frames of k contexts that share a device, as ONE launch: the CreatePyramids
+// (src/patch_match.cpp:61-76) of k trackers stepped together.  A pyramid kernel is a few microseconds of work behind a
+// launch: eight of them in a row cost 50-125 us of a 0.85 ms batched step (tools/batch_breakdown.py).  Per frame the same
+// bytes as its own launch (the same block body on the same arguments).
+int pagk_frame_set_device_batch(pagk_ctx *const *ctxs, int32_t k, const int32_t *slot, const void *const *d_data,
+                                const int32_t *width, const int32_t *height, const int64_t *step, int32_t pyramids)
+{
+    if (!ctxs || k < 1 || k > pagk_ctx::kBatchMaxStreams || !slot || !d_data || !width || !height || !step) return PAGK_E_ARG;
+    if (pyramids < 1 || pyramids > PAGK_MAX_PYRAMIDS) return PAGK_E_ARG;
+    for (int j = 0; j < k; j++) {
+        if (!ctxs[j] || slot[j] < 0 || slot[j] >= kUserSlots || !d_data[j] || width[j] < 1 || height[j] < 1 || step[j] < width[j]) return PAGK_E_ARG;
+        if (width[j] >= (1 << 24) || height[j] >= (1 << 24) || (int64_t)width[j] * height[j] >= (1ll << 31)) return PAGK_E_ARG;
+        for (int i = 0; i < j; i++)
+            if (ctxs[i] == ctxs[j] && slot[i] == slot[j]) return PAGK_E_ARG;   // (one frame per slot)
+    }
+    pagk_ctx *lead = ctxs[0];
+    for (int j = 1; j < k; j++)
+        if (ctxs[j]->device != lead->device) {
+            snprintf(lead->err, sizeof(lead->err), "pagk_frame_set_device_batch: context %d lives on device %d, the first on %d", j, ctxs[j]->device, lead->device);
+            return PAGK_E_ARG;
+        }
+    HIPCHK(lead, hipSetDevice(lead->device));
+    // the slots first (allocation, level pointers); then: can every frame go through the single-launch kernel?
+    bool fused = k > 1;
+    for (int j = 0; j < k; j++) {
+        pagk_ctx *c = ctxs[j];
+        FrameSlot &s = c->slots[slot[j]];
+        s.valid = false;
+        int rc = slot_reserve(c, s, width[j], height[j], pyramids);
+        if (rc) {
+            if (c != lead) snprintf(lead->err, sizeof(lead->err), "stream %d: %s", j, c->err);
+            return rc;
+        }
+        fused = fused && pyramid_fusable(s) && !c->unfused_pyramid;
+    }
+    if (!fused) {   // odd parents, more than four levels, a single frame: every frame as its own launch(es) on its own context
+        for (int j = 0; j < k; j++) {
+            pagk_ctx *c = ctxs[j];
+            FrameSlot &s = c->slots[slot[j]];
+            int rc = slot_build(c, s, static_cast<const uint8_t *>(d_data[j]), step[j], step[j] == width[j]);
+            s.pad0 = (int)(step[j] - width[j] > 2 ? 2 : step[j] - width[j]);
+            if (rc) {
+                if (c != lead) snprintf(lead->err, sizeof(lead->err), "stream %d: %s", j, c->err);
+                return rc;
+            }
+        }
+        return PAGK_OK;
+    }
+    int rc = PAGK_OK;
+    pagk_ctx::BatchDesc *desc = batch_desc_take(lead, &rc);
+    if (!desc) return rc;
+    PyrBatchEntry *he = static_cast<PyrBatchEntry *>(desc->host);
+    int nb = 0;
+    for (int j = 0; j < k; j++) {
+        FrameSlot &s = ctxs[j]->slots[slot[j]];
+        memset(&he[j], 0, sizeof he[j]);
+        he[j].block_base = nb;
+        nb += make_pyr_args(s, static_cast<const uint8_t *>(d_data[j]), step[j], step[j] == width[j], &he[j].a);
+    }
+    // the launch overwrites slots the other contexts' streams may still be reading, and reads images they may be writing ...
+    for (int j = 1; j < k; j++)
+        if (ctxs[j]->stream != lead->stream) {
+            HIPCHK(lead, hipEventRecord(ctxs[j]->ev_batch, ctxs[j]->stream));
+            HIPCHK(lead, hipStreamWaitEvent(lead->stream, ctxs[j]->ev_batch, 0));
+        }
+    HIPCHK(lead, hipMemcpyAsync(desc->dev, he, (size_t)k * sizeof(PyrBatchEntry), hipMemcpyHostToDevice, lead->stream));
+    if (lead->ev_pyr[0] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_pyr[0], lead->stream));
+    hipLaunchKernelGGL(k_pyramid_fused_batch, dim3(nb), dim3(256), 0, lead->stream, static_cast<const PyrBatchEntry *>(desc->dev), (int)k);
+    HIPCHK(lead, hipGetLastError());
+    if (lead->ev_pyr[1] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_pyr[1], lead->stream));
+    if (!in_capture(lead)) lead->pyr_timed = true;
+    if ((rc = batch_desc_used(lead, desc)) != PAGK_OK) return rc;
+    // ... and what those streams do next sees the pyramids
+    bool others = false;
+    for (int j = 1; j < k; j++) others = others || ctxs[j]->stream != lead->stream;
+    if (others) {
+        HIPCHK(lead, hipEventRecord(lead->ev_batch, lead->stream));
+        for (int j = 1; j < k; j++)
+            if (ctxs[j]->stream != lead->stream) HIPCHK(lead, hipStreamWaitEvent(ctxs[j]->stream, lead->ev_batch, 0));
+    }
+    for (int j = 0; j < k; j++) {
+        FrameSlot &s = ctxs[j]->slots[slot[j]];
+        s.wrap0 = step[j] == width[j];
+        s.pad0 = (int)(step[j] - width[j] > 2 ? 2 : step[j] - width[j]);
+        s.valid = true;
+    }
+    return PAGK_OK;
+}
+
 int pagk_frame_download_level(pagk_ctx *ctx, int32_t slot, int32_t level, uint8_t *dst, int32_t *width,
                               int32_t *height)
 {
@@ -1396,28 +1528,8 @@ int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params 
     a.batch_k = k;
     // the stream descriptors: pinned source -> device.  The copy is asynchronous and, inside a capture, a node that is
     // replayed later: the pair it uses is this launch's alone until the launch is over (ring) / the graph's (capture)
-    pagk_ctx::BatchDesc *desc = nullptr;
-    if (in_capture(lead)) {
-        if (!lead->capturing || lead->cap_batch_used >= (int)lead->cap_batch.size()) {
-            snprintf(lead->err, sizeof(lead->err), "a batched launch inside a graph capture needs descriptor buffers reserved by pagk_graph_begin of "
-                     "ctxs[0]: issue the batched call once before capturing, capture through pagk_graph_begin(ctxs[0]), at most %d batched calls per capture",
-                     pagk_ctx::kBatchPerCapture);
-            return PAGK_E_ARG;
-        }
-        desc = &lead->cap_batch[lead->cap_batch_used++];
-    } else {
-        desc = &lead->batch_ring[lead->batch_turn];
-        lead->batch_turn = (lead->batch_turn + 1) % pagk_ctx::kBatchRing;
-        if (!desc->dev) {
-            if (int ar = batch_desc_alloc(lead, *desc)) {
-                batch_desc_free(*desc);
-                return ar;
-            }
-        } else if (desc->recorded) {
-            HIPCHK(lead, hipEventSynchronize(desc->used));   // (the launch four calls ago)
-        }
-        lead->batch_seen = true;
-    }
+    pagk_ctx::BatchDesc *desc = batch_desc_take(lead, &rc);
+    if (!desc) return rc;
     BatchStream *hb = static_cast<BatchStream *>(desc->host);
     int qb = 0;
     for (int j = 0; j < k; j++) {
@@ -1491,10 +1603,7 @@ int pagk_track_device_batch(pagk_ctx *const *ctxs, int32_t k, const pagk_params 
     else if (a.half == 7) e = lean ? launch(k_track_quad<4, true, true, true>) : launch(k_track_quad<4, false, true, true>);
     else e = lean ? launch(k_track_quad<7, true, true, true>) : launch(k_track_quad<7, false, true, true>);
     HIPCHK(lead, e);
-    if (!in_capture(lead)) {
-        HIPCHK(lead, hipEventRecord(desc->used, lead->stream));
-        desc->recorded = true;
-    }
+    if ((rc = batch_desc_used(lead, desc)) != PAGK_OK) return rc;
     if (lead->ev_trk[1] && !in_capture(lead)) HIPCHK(lead, hipEventRecord(lead->ev_trk[1], lead->stream));
     if (!in_capture(lead)) lead->trk_timed = true;
     // ... and whatever those streams do next sees its results

@@ -167,6 +167,20 @@ __global__ void __launch_bounds__(256) k_pyramid_fused(PyrArgs a)
     pyr_block(a, (int)blockIdx.x, (int)threadIdx.x);
 }
 
+// The pyramids of k frames as ONE launch (pagk_frame_set_device_batch: the CreatePyramids of k trackers that are stepped
+// together, src/patch_match.cpp:61-76 per tracker): a block finds its frame by the frames' first blocks (ascending;
+// wave-uniform scalar loads), then runs k_pyramid_fused's body on it -- per frame the same bytes as its own launch.
+struct PyrBatchEntry {
+    PyrArgs a;
+    int block_base, pad_;
+};
+__global__ void __launch_bounds__(256) k_pyramid_fused_batch(const PyrBatchEntry *__restrict__ frames, int k)
+{
+    int f = 0;
+    for (int j = 1; j < k; j++) f = (int)blockIdx.x >= frames[j].block_base ? j : f;
+    pyr_block(frames[f].a, (int)blockIdx.x - frames[f].block_base, (int)threadIdx.x);
+}
+
 // ---- GyroPredictFeatures (src/gyro_aided_tracker.cpp:118-185,194-231), one thread per feature ----
 struct PredictArgs {
     int n, width, height;

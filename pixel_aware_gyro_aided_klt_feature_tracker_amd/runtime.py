@@ -405,8 +405,8 @@ class CameraBatch:
     """k camera streams that share ONE GPU, stepped as one launch: BASELINE configs[4], "batched multi-camera: concurrent
     streams, hipGraph-captured iterate".  The reference builds one PatchMatch per tracker
     (src/gyro_aided_tracker.cpp:276-283); here every stream is a ResidentTracker (its own context: frame slots, feature
-    arrays, outputs), all switched to ONE stream, and a step is [the k current frames' pyramids, then
-    pagk_track_device_batch] -- replayed as one hipGraph after the first step, or issued directly."""
+    arrays, outputs), all switched to ONE stream, and a step is [the k current frames' pyramids as one launch
+    (pagk_frame_set_device_batch), then pagk_track_device_batch] -- replayed as one hipGraph after the first step, or issued directly."""
 
     def __init__(self, params: capi.Params, k: int, device: int = 0):
         self.params = params
@@ -436,9 +436,10 @@ class CameraBatch:
         self._drop_graph()
 
     def _issue(self):
-        for c in self.cams:
-            c.rebuild_current_pyramid(1)
         cs = self.cams
+        # the k current frames' pyramids as one launch, then the k trackers' PatchMatch as one launch
+        capi.Context.frame_set_device_batch([c.ctx for c in cs], [1] * len(cs), [c.img_cur.data_ptr() for c in cs],
+                                            [c.w for c in cs], [c.h for c in cs], [c.w for c in cs], self.params.pyramids)
         capi.Context.track_device_batch([c.ctx for c in cs], self.params, [0] * len(cs), [1] * len(cs),
                                         [c.hi - c.lo for c in cs], [c.d_pt_ref for c in cs], [c.d_pt_init for c in cs],
                                         [c.d_affine for c in cs], [c.d_status for c in cs], [c.out for c in cs])

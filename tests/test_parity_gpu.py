@@ -492,6 +492,56 @@ def test_odd_sized_images(ctx, width, height, L):
     assert ref["status"][:w.n].sum() > 150
 
 
+@pytest.mark.parametrize("shapes,L", [([(1280, 720), (640, 480), (752, 480), (64, 48), (1920, 1080)], 3),
+                                      ([(640, 480), (160, 120), (1024, 512)], 4),
+                                      ([(640, 480), (161, 121), (320, 240)], 3),      # an odd parent: k per-context launches
+                                      ([(752, 480)], 3)])
+def test_batched_pyramids_equal_every_contexts_own(shapes, L):
+    """pagk_frame_set_device_batch: the pyramids of k contexts' frames as ONE launch -- every level of every frame must be
+    the bytes of the oracle's cv::resize restatement (= of the context's own pagk_frame_set_device), for frames of
+    different sizes, with a padded source (step > width), twice in a row with different images (the descriptor ring),
+    and on the fallback path (a frame the single-launch kernel does not serve)."""
+    cs = [capi.Context(0) for _ in shapes]
+    try:
+        rng = np.random.default_rng(len(shapes) * 131 + L)
+        for rep in range(3):
+            imgs, devs, steps = [], [], []
+            for j, (wd, ht) in enumerate(shapes):
+                pad = 0 if j % 2 == 0 else 5                     # odd streams: rows `pad` bytes apart from the next
+                full = rng.integers(0, 256, size=(ht, wd + pad), dtype=np.uint8)
+                d = torch.from_numpy(full).to("cuda:0")
+                devs.append(d)
+                imgs.append(np.ascontiguousarray(full[:, :wd]))
+                steps.append(wd + pad)
+            torch.cuda.synchronize()
+            capi.Context.frame_set_device_batch(cs, [2] * len(cs), [d.data_ptr() for d in devs], [s[0] for s in shapes],
+                                                [s[1] for s in shapes], steps, L)
+            for j, (c, (wd, ht)) in enumerate(zip(cs, shapes)):
+                c.sync()
+                lvl = imgs[j]
+                for l in range(1, L):
+                    lvl = orc.pyr_down(lvl)
+                    assert np.array_equal(c.frame_download_level(2, l, wd, ht), lvl), f"rep {rep}, frame {j} ({wd}x{ht}), level {l}"
+        # and the packed taps: track on the batch-built slot against the oracle (level 0's quads are only visible this way)
+        w = synth.make_workload("bp", shapes[0][0], shapes[0][1], 200, seed=0xB9, half_patch=7, iterations=15, pyramids=L)
+        p = params_for(w)
+        dr, dc = torch.from_numpy(w.img_ref).to("cuda:0"), torch.from_numpy(w.img_cur).to("cuda:0")
+        dev = torch.device("cuda:0")
+        capi.Context.frame_set_device_batch(cs[:1] * 1 + cs[1:], [0] * len(cs), [dr.data_ptr()] + [d.data_ptr() for d in devs[1:]],
+                                            [s[0] for s in shapes], [s[1] for s in shapes], [shapes[0][0]] + steps[1:], L)
+        capi.Context.frame_set_device_batch(cs, [1] * len(cs), [dc.data_ptr()] + [d.data_ptr() for d in devs[1:]],
+                                            [s[0] for s in shapes], [s[1] for s in shapes], [shapes[0][0]] + steps[1:], L)
+        out = distributed.alloc_device_outputs(w.n, dev)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        cs[0].track_device(p, 0, 1, w.n, up(w.pt_ref), up(w.pt_init), up(w.affine), up(w.status_in), out)
+        cs[0].sync()
+        ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert_parity({k: out[k].cpu().numpy() for k, _, _ in distributed.FIELDS}, ref, w.n, exact=True, what="tracking on batch-built pyramids")
+    finally:
+        for c in cs:
+            c.close()
+
+
 def test_caller_built_pyramids(ctx):
     w = synth.make_workload("pyr", 320, 240, 40, seed=0x5EED0500, half_patch=5, iterations=10, pyramids=3)
     p = params_for(w)
