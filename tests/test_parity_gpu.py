@@ -527,7 +527,7 @@ def test_batched_pyramids_equal_every_contexts_own(shapes, L):
         p = params_for(w)
         dr, dc = torch.from_numpy(w.img_ref).to("cuda:0"), torch.from_numpy(w.img_cur).to("cuda:0")
         dev = torch.device("cuda:0")
-        capi.Context.frame_set_device_batch(cs[:1] * 1 + cs[1:], [0] * len(cs), [dr.data_ptr()] + [d.data_ptr() for d in devs[1:]],
+        capi.Context.frame_set_device_batch(cs, [0] * len(cs), [dr.data_ptr()] + [d.data_ptr() for d in devs[1:]],
                                             [s[0] for s in shapes], [s[1] for s in shapes], [shapes[0][0]] + steps[1:], L)
         capi.Context.frame_set_device_batch(cs, [1] * len(cs), [dc.data_ptr()] + [d.data_ptr() for d in devs[1:]],
                                             [s[0] for s in shapes], [s[1] for s in shapes], [shapes[0][0]] + steps[1:], L)
