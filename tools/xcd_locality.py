@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pixel_aware_gyro_aided_klt_feature_tracker_amd import capi, synth
 ctx = capi.Context(0)
-for cfg, n in ((1, 1000), (1, 4000), (3, 20000)):
+for cfg, n in [tuple(int(v) for v in c.split(':')) for c in os.environ.get('PAGK_CASES', '1:1000,1:4000,3:20000').split(',')]:
     w = synth.config(cfg, n=n)
     p = capi.make_params(half_patch=w.half_patch, iterations=w.iterations, pyramids=w.pyramids, has_gyro=w.has_gyro, camera=w.camera)
     order = np.argsort(w.pt_ref[:, 1], kind="stable")            # by y
@@ -17,7 +17,13 @@ for cfg, n in ((1, 1000), (1, 4000), (3, 20000)):
     rest = np.concatenate([b[m:] for b in bands])
     banded = np.concatenate([inter, rest]).astype(np.int64)
     rng = np.random.default_rng(0)
-    perms = {"generator": np.arange(w.n), "banded": banded, "sorted_y": order, "shuffled": rng.permutation(w.n)}
+    # variant 7 hands QUADS (four consecutive features) to its eight ticket sequences, quad q -> sequence q % 8 -> the XCD
+    # that starts with that sequence: band k's features in groups of four at positions 32 j + 4 k + i
+    m4 = m // 4 * 4
+    bq = np.stack([b[:m4].reshape(-1, 4) for b in bands], axis=1).reshape(-1)
+    banded_quads = np.concatenate([bq, np.concatenate([b[m4:] for b in bands])]).astype(np.int64)
+    perms = {"generator": np.arange(w.n), "banded": banded, "banded_quads": banded_quads, "sorted_y": order,
+             "shuffled": rng.permutation(w.n)}
     line = f"cfg{cfg} n={n}:"
     for rep in range(2):
         for name, perm in perms.items():
