@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "pagk_device.h"
 #include "pagk_chain_asm.h"
+#include "pagk_prio.h"
 
 namespace pagk {
 
@@ -678,6 +679,8 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     }
 
     int succ = 1, iters = 0;
+    constexpr bool kPrioByWork = NR > 1;  // pagk_prio.h
+    PAGK_PRIO_DECL
     float lastCost = 0.0f;
 #ifdef PAGK_STAMPS
     // diagnostic build only: cycles per phase, summed over iterations, written to a.dbg (a buffer
@@ -754,6 +757,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
         STAMP(0)
         for (int iter = iter_first; iter < a.iterations; iter++) {  // :215
             iters++;
+            PAGK_PRIO_TIER  // (pagk_prio.h: a workgroup that is behind its neighbours outranks them)
             // ---- 1. sampling ------------------------------------------------------------------
             const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
             const float gain = 1.0f + dg;
@@ -903,7 +907,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
             // the dependent chain and the solve are a feature's critical path: while they run, this wave wins
             // issue arbitration over co-resident waves that are sampling (s_setprio; arithmetic untouched).
             // Measured A/B in one session (tools/ab_lib.py): -1 % at 1000 features, -2.4 % at 4000.
-            __builtin_amdgcn_s_setprio(3);
+            PRIO(PAGK_PRIO_N_CHAIN)
             // ---- 2. ordered accumulation (:284-299) -------------------------------------------
             if constexpr (MFMA) {
                 if (wave == 0) {
@@ -1048,7 +1052,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                 }
             }
             __syncthreads();
-            __builtin_amdgcn_s_setprio(0);
+            PRIO(0)
             STAMP(3)
             // ---- 4. update + termination, identically in every lane (:322-344) -----------------
             // (the compiler sinks these reads behind the exit tests that precede their first use: three LDS round trips;
@@ -1079,6 +1083,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
         // the next level's first sampling pass overwrites the streams: every lane left the loop
         // after the same barrier, and cslot is rewritten before the next pass's first barrier.
     }
+    PAGK_PRIO_RESET
     float ncc = 1.0f;  // :365
     if (a.calc_ncc) {
         // PatchMatch::NCC (:433-469) on the level-0 images at the final point.  Same structure as an

@@ -126,6 +126,8 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
     const int acc_slot = wave < 2 ? (lr == 0 ? (cid == 7 ? 9 : cid) : ((lr == 1 && cid >= 5) ? (cid == 7 ? 10 : cid + 2) : -1)) : -1;
 
     int succ = 1, iters = 0, seq = 0;
+    constexpr bool kPrioByWork = true;  // pagk_prio.h
+    PAGK_PRIO_DECL
     float lastCost = 0.0f;
 #ifdef PAGK_STAMPS
     // diagnostic build only (tools/stamps.py): cycles per phase as wave 0 sees them, summed over iterations.
@@ -209,6 +211,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
         for (int iter = iter_first; iter < a.iterations; iter++) {  // :215
             iters++;
             seq++;
+            PAGK_PRIO_TIER
             POINT(0)
             // ---- round 0 of the sampling: pixel tid ----------------------------------------------
             const float bx = ptx + dx, by = pty + dy;  // (pt.x + dx), then + wx (:252)
@@ -249,7 +252,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
             POINT(1)
             if (wave < 2) {
                 // ---- ordered accumulation (:284-299), the feature's critical path: wins issue arbitration ----------
-                __builtin_amdgcn_s_setprio(3);
+                PRIO(PAGK_PRIO_N_CHAIN)
                 // (the iteration number is the same in every lane, but the loop's exits depend on values read from LDS, so the
                 // compiler may carry it in a vector register -- and an "s" operand of inline asm is taken as is: seen when
                 // this body was instantiated inside another kernel, profiles/r04_lead_pyramid_experiment.patch)
@@ -263,7 +266,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     asm volatile("" ::: "memory");
                     if (lane == 0) reinterpret_cast<volatile int *>(flags)[2] = seq;
                     STAMP(4)   // (wave 1) B1 -> its accumulators published
-                    __builtin_amdgcn_s_setprio(0);
+                    PRIO(0)
                     if (iter == iter_first && level > 0) {
                         // the next level's H22, in the shadow of this solve: c = -I1(pt) there (:263), same expressions
                         // as that level's set-up
@@ -337,12 +340,12 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                             if constexpr (!LEAN) sh_pen[0] = epsq;
                         }
                     }
-                    __builtin_amdgcn_s_setprio(0);
+                    PRIO(0)
                     POINT(3)
                 }
             } else if (wave == 2) {
                 // ---- round 1, batches A and C: both batches' gathers in flight together ----------------------------
-                __builtin_amdgcn_s_setprio(2);
+                PRIO(PAGK_PRIO_N_SAMP)
                 auto round1 = [&](auto clamp_tag) {
                     constexpr bool CL = decltype(clamp_tag)::value;
                     const FiveTaps ta = sample5_issue<CL>(L2, bx + wx[1], by + wy[1]);
@@ -366,11 +369,11 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     round1(std::false_type{});
                 else
                     round1(std::true_type{});
-                __builtin_amdgcn_s_setprio(0);
+                PRIO(0)
             } else {
                 // ---- round 1, batch B; then the ordered f32 cost sum (:294) -----------------------------------------
                 if constexpr (HAS_B) {
-                    __builtin_amdgcn_s_setprio(2);
+                    PRIO(PAGK_PRIO_N_SAMP)
                     if (interior) {
                         const FiveTaps tb = sample5_issue<false>(L2, bx + wx[1], by + wy[1]);
                         emit(tb, pix[1], s1[1]);
@@ -382,12 +385,12 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     if (lane == 0) atomicAdd(flags, 1);
                     STAMP(10)   // (wave 3) B1 -> batch B published
                 }
-                __builtin_amdgcn_s_setprio(1);
+                PRIO(PAGK_PRIO_N_COST)
                 const float c = chain_rows_f32_piped<H>(row_addr, flag_addr, (uint32_t)__builtin_amdgcn_readfirstlane((HAS_B ? 2 : 1) * seq),
                                                         (uint32_t)__builtin_amdgcn_readfirstlane(seq));
                 if (lane == 0) sh_cost[0] = c;
                 STAMP(13)   // (wave 3) B published -> cost published
-                __builtin_amdgcn_s_setprio(0);
+                PRIO(0)
             }
             __syncthreads();  // B2: update, cost (and h22 of the next level) are in LDS; every reader of this iteration's streams is done
             STAMP(3)
@@ -425,6 +428,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
         p2y = pty + dy;
         // the next level's round 0 overwrites the streams: every lane left the loop after B2
     }
+    PAGK_PRIO_RESET
     float ncc = 1.0f;  // :365
     if (a.calc_ncc) {
         // PatchMatch::NCC (:433-469) on the level-0 images at the final point, as in track_block_body: every lane samples

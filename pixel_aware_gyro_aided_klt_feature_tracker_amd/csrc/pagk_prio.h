@@ -1,0 +1,55 @@
+// pagk_prio.h -- issue priority of a 4-wave workgroup's waves (s_setprio; arithmetic untouched).
+//
+// A launch of the 4-wave kernels lasts as long as its slowest feature, and while a CU holds four workgroups the
+// iteration of every one of them is stretched from 6.1 k to 10.6 k cycles: the feature that
+// will need 26 iterations pays for the company of three that need 10.  Which feature that is cannot be known in
+// advance, but it shows: all workgroups of a launch start together and iterate at the same pace, so one that has used
+// more iterations than PAGK_PRIO_K per pyramid level it has entered is BEHIND its neighbours and has the most work
+// left.  Longest-remaining-work-first is the makespan rule: a workgroup that is behind runs every phase at priority 3,
+// the others keep the by-phase priorities below it (ordered chains 2, second sampling round 1, cost chain 1, the rest
+// 0) and lose only issue slots they had slack for.  K = 4: the mean of the BASELINE workloads is 3.5 iterations per
+// level.  Measured in one session (profiles/r04_ab8_priority_by_remaining_work.log): 1000 features 97.9 -> 87.4 us,
+// 500: 75.4 -> 72.1, configs[2] 2000 x 4 levels 208 -> 199.5, 250 (nothing to outrank) 69.5 -> 69.9.
+// A body states with `constexpr bool kPrioByWork` whether the rule applies to it: not for one-round patches (h <= 7: five
+// workgroups of 96 VGPRs per CU, short iterations -- 0..+1.7 % there).
+// -DPAGK_PRIO_MODE=0 is the by-phase rule alone (rounds 1-4: chains 3, sampling 2, cost 1).
+#pragma once
+
+#ifndef PAGK_PRIO_MODE
+#define PAGK_PRIO_MODE 1
+#endif
+#ifndef PAGK_PRIO_K
+#define PAGK_PRIO_K 4
+#endif
+#if PAGK_PRIO_MODE == 0
+#define PAGK_PRIO_DECL
+#define PAGK_PRIO_TIER
+#define PAGK_PRIO_RESET
+#define PRIO(n) __builtin_amdgcn_s_setprio(n);
+#define PAGK_PRIO_N_CHAIN 3
+#define PAGK_PRIO_N_SAMP 2
+#define PAGK_PRIO_N_COST 1
+#else
+#define PAGK_PRIO_DECL int tier_now = 0;
+// (wave-uniform: iters, level and the kernel argument are the same in every lane)
+#define PAGK_PRIO_TIER                                                              \
+    const int tier = (kPrioByWork && iters > PAGK_PRIO_K * (a.n_levels - level)) ? 3 : 0;  \
+    if (tier != tier_now) {                                                         \
+        tier_now = tier;                                                            \
+        if (tier == 3) {                                                            \
+            __builtin_amdgcn_s_setprio(3);                                          \
+        } else {                                                                    \
+            __builtin_amdgcn_s_setprio(0);                                          \
+        }                                                                           \
+    }
+// by-phase priority of a workgroup that is not behind
+#define PRIO(n)                                 \
+    if (tier == 0) {                            \
+        __builtin_amdgcn_s_setprio(n);          \
+    }
+// (a finisher runs a body once per feature)
+#define PAGK_PRIO_RESET __builtin_amdgcn_s_setprio(0);
+#define PAGK_PRIO_N_CHAIN 2
+#define PAGK_PRIO_N_SAMP 1
+#define PAGK_PRIO_N_COST 1
+#endif
