@@ -679,7 +679,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
     }
 
     int succ = 1, iters = 0;
-    constexpr bool kPrioByWork = NR > 1;  // pagk_prio.h
+    [[maybe_unused]] constexpr bool kPrioByWork = NR > 1;  // pagk_prio.h
     PAGK_PRIO_DECL
     float lastCost = 0.0f;
 #ifdef PAGK_STAMPS

@@ -126,7 +126,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
     const int acc_slot = wave < 2 ? (lr == 0 ? (cid == 7 ? 9 : cid) : ((lr == 1 && cid >= 5) ? (cid == 7 ? 10 : cid + 2) : -1)) : -1;
 
     int succ = 1, iters = 0, seq = 0;
-    constexpr bool kPrioByWork = true;  // pagk_prio.h
+    [[maybe_unused]] constexpr bool kPrioByWork = true;  // pagk_prio.h
     PAGK_PRIO_DECL
     float lastCost = 0.0f;
 #ifdef PAGK_STAMPS
