@@ -1052,7 +1052,7 @@ __device__ __forceinline__ void track_block_body(const TrackArgs &a, const int i
                 }
             }
             __syncthreads();
-            PRIO(0)
+            PRIO(PAGK_PRIO_N_REST)
             STAMP(3)
             // ---- 4. update + termination, identically in every lane (:322-344) -----------------
             // (the compiler sinks these reads behind the exit tests that precede their first use: three LDS round trips;

@@ -266,7 +266,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     asm volatile("" ::: "memory");
                     if (lane == 0) reinterpret_cast<volatile int *>(flags)[2] = seq;
                     STAMP(4)   // (wave 1) B1 -> its accumulators published
-                    PRIO(0)
+                    PRIO(PAGK_PRIO_N_REST)
                     if (iter == iter_first && level > 0) {
                         // the next level's H22, in the shadow of this solve: c = -I1(pt) there (:263), same expressions
                         // as that level's set-up
@@ -340,7 +340,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                             if constexpr (!LEAN) sh_pen[0] = epsq;
                         }
                     }
-                    PRIO(0)
+                    PRIO(PAGK_PRIO_N_REST)
                     POINT(3)
                 }
             } else if (wave == 2) {
@@ -369,7 +369,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                     round1(std::false_type{});
                 else
                     round1(std::true_type{});
-                PRIO(0)
+                PRIO(PAGK_PRIO_N_REST)
             } else {
                 // ---- round 1, batch B; then the ordered f32 cost sum (:294) -----------------------------------------
                 if constexpr (HAS_B) {
@@ -390,7 +390,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                                                         (uint32_t)__builtin_amdgcn_readfirstlane(seq));
                 if (lane == 0) sh_cost[0] = c;
                 STAMP(13)   // (wave 3) B published -> cost published
-                PRIO(0)
+                PRIO(PAGK_PRIO_N_REST)
             }
             __syncthreads();  // B2: update, cost (and h22 of the next level) are in LDS; every reader of this iteration's streams is done
             STAMP(3)

@@ -29,6 +29,7 @@
 #define PAGK_PRIO_N_CHAIN 3
 #define PAGK_PRIO_N_SAMP 2
 #define PAGK_PRIO_N_COST 1
+#define PAGK_PRIO_N_REST 0
 #else
 #define PAGK_PRIO_DECL int tier_now = 0;
 // (wave-uniform: iters, level and the kernel argument are the same in every lane)
@@ -52,4 +53,5 @@
 #define PAGK_PRIO_N_CHAIN 2
 #define PAGK_PRIO_N_SAMP 1
 #define PAGK_PRIO_N_COST 1
+#define PAGK_PRIO_N_REST 0
 #endif
