@@ -48,6 +48,12 @@ __device__ __forceinline__ bool lds_wait_ge(const int *flag, int want)
     return false;
 }
 
+// a flag word behind the data it vouches for: every lane stores the same value to the same address (no exec juggling)
+__device__ __forceinline__ void lds_store_b32(uint32_t addr, int v)
+{
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
 template <int H, bool LEAN>
 __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i, const SuspState *resume = nullptr)
 {
@@ -263,8 +269,9 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                 if (wave == 1) {
                     // the flag right behind the sums: LDS executes one wave's instructions in order, so whoever reads the
                     // flag's new value reads the sums stored before it (no s_waitcnt in between: it would only delay the flag)
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) reinterpret_cast<volatile int *>(flags)[2] = seq;
+                    // (an explicit ds_write: through a volatile pointer the compiler stored with flat_store_dword sc0 sc1 +
+                    // s_waitcnt vmcnt(0) -- the flat path into LDS, on the way from wave 1's sums to wave 0's solve)
+                    lds_store_b32(flag_addr + 8u, seq);
                     STAMP(4)   // (wave 1) B1 -> its accumulators published
                     PRIO(PAGK_PRIO_N_REST)
                     if (iter == iter_first && level > 0) {
@@ -357,7 +364,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
                         STAMP(8)   // (wave 2) B1 -> batch A published
                         emit(tc, pix[2], s1[2]);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) reinterpret_cast<volatile int *>(flags)[1] = seq;
+                        lds_store_b32(flag_addr + 4u, seq);
                         STAMP(9)   // (wave 2) A published -> C published
                     } else {
                         emit(ta, pix[1], s1[1]);

@@ -32,22 +32,33 @@
 #define PAGK_PRIO_N_REST 0
 #else
 #define PAGK_PRIO_DECL int tier_now = 0;
-// (wave-uniform: iters, level and the kernel argument are the same in every lane)
-#define PAGK_PRIO_TIER                                                              \
-    const int tier = (kPrioByWork && iters > PAGK_PRIO_K * (a.n_levels - level)) ? 3 : 0;  \
-    if (tier != tier_now) {                                                         \
-        tier_now = tier;                                                            \
-        if (tier == 3) {                                                            \
-            __builtin_amdgcn_s_setprio(3);                                          \
-        } else {                                                                    \
-            __builtin_amdgcn_s_setprio(0);                                          \
-        }                                                                           \
+#define PAGK_STR2(x) #x
+#define PAGK_STR(x) PAGK_STR2(x)
+// (wave-uniform: iters, level and the kernel argument are the same in every lane; readfirstlane says so to the compiler, and
+// the branches are written out -- as C the comparison was carried as a lane mask and every site cost a VALU compare or two)
+// The priority is switched once per transition: two scalar instructions on the path of an iteration without one.
+#define PAGK_PRIO_TIER                                                                                              \
+    {                                                                                                               \
+        const int tier = (kPrioByWork && __builtin_amdgcn_readfirstlane(iters - PAGK_PRIO_K * (a.n_levels - level)) > 0) ? 3 : 0; \
+        asm volatile("s_cmp_eq_u32 %0, %1\n\t"                                                                      \
+                     "s_cbranch_scc1 2f\n\t"                                                                        \
+                     "s_cmp_eq_u32 %1, 0\n\t"                                                                       \
+                     "s_cbranch_scc1 1f\n\t"                                                                        \
+                     "s_setprio 3\n\t"                                                                              \
+                     "s_branch 2f\n"                                                                                \
+                     "1:\n\t"                                                                                       \
+                     "s_setprio 0\n"                                                                                \
+                     "2:" ::"s"(tier_now), "s"(tier)                                                                \
+                     : "scc");                                                                                      \
+        tier_now = tier;                                                                                            \
     }
-// by-phase priority of a workgroup that is not behind
-#define PRIO(n)                                 \
-    if (tier == 0) {                            \
-        __builtin_amdgcn_s_setprio(n);          \
-    }
+// by-phase priority of a workgroup that is not behind: one guarded s_setprio
+#define PRIO(n)                                                                                                     \
+    asm volatile("s_cmp_lg_u32 %0, 0\n\t"                                                                           \
+                 "s_cbranch_scc1 1f\n\t"                                                                            \
+                 "s_setprio " PAGK_STR(n) "\n"                                                                      \
+                 "1:" ::"s"(tier_now)                                                                               \
+                 : "scc");
 // (a finisher runs a body once per feature)
 #define PAGK_PRIO_RESET __builtin_amdgcn_s_setprio(0);
 #define PAGK_PRIO_N_CHAIN 2
