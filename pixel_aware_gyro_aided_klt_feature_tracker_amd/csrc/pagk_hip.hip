@@ -126,6 +126,7 @@ struct pagk_ctx {
     int wave_min_features = 6000;        // PAGK_WAVE_MIN (5000 until the 4-wave kernel had its build for five workgroups per CU)
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int block5_min_features = 2500;      // PAGK_BLOCK5_MIN: the 4-wave kernel in its five-workgroups-per-CU build (h = 10)
+    bool block5_window = true;           // ... also for launches that only five workgroups per CU hold in one round (off when PAGK_BLOCK5_MIN is set)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
     int levels_shift = 0;                // PAGK_LEVELS_XCD_SHIFT (tests): waves start with another XCD's ticket sequence
     bool levels_shared = false;          // PAGK_LEVELS_SHARED=1 (measurement): ... also for contexts that share the device
@@ -895,7 +896,12 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
                 case 201: e = lean ? launch(k_track_block<2, 1, 4, false, false, true>) : launch(k_track_block<2, 1>); break;    // h = 8
                 case 209: e = lean ? launch(k_track_block<2, 9, 4, false, false, true>) : launch(k_track_block<2, 9>); break;    // h = 9
                 case 225:   // h = 10; several rounds of workgroups: the build for five workgroups per CU
-                    e = lean ? (n >= ctx->block5_min_features ? launch(k_track_block5<2, 25, true>) : launch(k_track_block<2, 25, 4, false, false, true>))
+                    // ... and a launch that five workgroups per CU hold at once but four do not (1025..1280 features on 256 CUs:
+                    // one round instead of two, 104 -> 97 us at 1100 features; from 1300 on the pipelined kernel is
+                    // equal or faster again, profiles/r04_block5_sweep_1100_3000.log)
+                    e = lean ? ((n >= ctx->block5_min_features || (ctx->block5_window && n > 4 * ctx->cus && n <= 5 * ctx->cus))
+                                    ? launch(k_track_block5<2, 25, true>)
+                                    : launch(k_track_block<2, 25, 4, false, false, true>))
                              : launch(k_track_block<2, 25>);
                     break;
                 case 317: e = lean ? launch(k_track_block<3, 17, 4, false, false, true>) : launch(k_track_block<3, 17>); break;   // h = 11, 12
@@ -1127,7 +1133,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_MFMA_MIN")) ctx->mfma_min_features = atoi(getenv("PAGK_MFMA_MIN"));
     if (getenv("PAGK_WAVE_MIN")) ctx->wave_min_features = atoi(getenv("PAGK_WAVE_MIN"));
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
-    if (getenv("PAGK_BLOCK5_MIN")) ctx->block5_min_features = atoi(getenv("PAGK_BLOCK5_MIN"));
+    if (getenv("PAGK_BLOCK5_MIN")) ctx->block5_min_features = atoi(getenv("PAGK_BLOCK5_MIN")), ctx->block5_window = false;
     if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
     if (getenv("PAGK_LEVELS_XCD_SHIFT")) ctx->levels_shift = atoi(getenv("PAGK_LEVELS_XCD_SHIFT")) & 7;
     if (getenv("PAGK_LEVELS_SHARED")) ctx->levels_shared = atoi(getenv("PAGK_LEVELS_SHARED")) != 0;

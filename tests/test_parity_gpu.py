@@ -360,6 +360,17 @@ def test_baseline_configs_against_oracle(ctx, idx, n):
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("n", [1100, 1280, 1281, 2600])
+def test_launch_sizes_around_the_five_workgroups_per_cu_window(ctx, n):
+    # automatic selection at h = 10: the pipelined 4-wave kernel up to 4 workgroups per CU, its five-per-CU build for what
+    # only five hold in one round (1025..1280 features on 256 CUs), the pipelined kernel again, the five-per-CU build from
+    # 2500 (csrc/pagk_hip.hip, profiles/r04_block5_sweep_1100_3000.log): the same bits as the oracle whichever runs
+    w = synth.config(1, n=n)
+    got, ref = run_both(ctx, params_for(w), w, nthreads=8)
+    assert_parity(got, ref, w.n, exact=True, what=f"configs[1] x {n}")
+    assert ctx.last_variant() == 0
+
+
 @pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15])
 def test_every_patch_size(ctx, h):
     # every (NR, TAIL) instantiation of k_track_block
