@@ -101,6 +101,7 @@ struct TrackArgs {
     const BatchStream *batch;  // batched launch: batch_k streams (device memory); n is then 4 x the batch's quads
     int batch_k;
     int half, iterations;
+    int prio_k;  // pagk_prio.h: a 4-wave workgroup past prio_k iterations per level entered is behind (0: never)
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

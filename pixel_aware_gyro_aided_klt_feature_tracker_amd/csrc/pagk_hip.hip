@@ -126,6 +126,7 @@ struct pagk_ctx {
     int wave_min_features = 6000;        // PAGK_WAVE_MIN (5000 until the 4-wave kernel had its build for five workgroups per CU)
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int block5_min_features = 2500;      // PAGK_BLOCK5_MIN: the 4-wave kernel in its five-workgroups-per-CU build (h = 10)
+    int prio_k = 4;                      // PAGK_PRIO_K: iterations per pyramid level beyond which a 4-wave workgroup counts as behind (pagk_prio.h); 0 = rule off
     bool block5_window = true;           // ... also for launches that only five workgroups per CU hold in one round (off when PAGK_BLOCK5_MIN is set)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
     int levels_shift = 0;                // PAGK_LEVELS_XCD_SHIFT (tests): waves start with another XCD's ticket sequence
@@ -581,6 +582,7 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
     a.dbg = reinterpret_cast<unsigned long long *>(getenv("PAGK_DBG_PTR") ? strtoull(getenv("PAGK_DBG_PTR"), nullptr, 0) : 0ull);
 #endif
     fill_param_args(a, p);
+    a.prio_k = ctx->prio_k;
 
     if (ctx->ev_trk[0] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
     if (n > 0) {
@@ -1135,6 +1137,7 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     if (getenv("PAGK_BLOCK5_MIN")) ctx->block5_min_features = atoi(getenv("PAGK_BLOCK5_MIN")), ctx->block5_window = false;
     if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
+    if (getenv("PAGK_PRIO_K")) ctx->prio_k = atoi(getenv("PAGK_PRIO_K")) < 0 ? 0 : atoi(getenv("PAGK_PRIO_K"));
     if (getenv("PAGK_LEVELS_XCD_SHIFT")) ctx->levels_shift = atoi(getenv("PAGK_LEVELS_XCD_SHIFT")) & 7;
     if (getenv("PAGK_LEVELS_SHARED")) ctx->levels_shared = atoi(getenv("PAGK_LEVELS_SHARED")) != 0;
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));

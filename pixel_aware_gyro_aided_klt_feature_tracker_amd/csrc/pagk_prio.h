@@ -4,7 +4,7 @@
 // iteration of every one of them is stretched from 6.1 k to 10.6 k cycles: the feature that
 // will need 26 iterations pays for the company of three that need 10.  Which feature that is cannot be known in
 // advance, but it shows: all workgroups of a launch start together and iterate at the same pace, so one that has used
-// more iterations than PAGK_PRIO_K per pyramid level it has entered is BEHIND its neighbours and has the most work
+// more iterations than K (TrackArgs::prio_k: 4, PAGK_PRIO_K in the environment of pagk_create, 0 = off) per pyramid level it has entered is BEHIND its neighbours and has the most work
 // left.  Longest-remaining-work-first is the makespan rule: a workgroup that is behind runs every phase at priority 3,
 // the others keep the by-phase priorities below it (ordered chains 2, second sampling round 1, cost chain 1, the rest
 // 0) and lose only issue slots they had slack for.  K = 4: the mean of the BASELINE workloads is 3.5 iterations per
@@ -17,9 +17,6 @@
 
 #ifndef PAGK_PRIO_MODE
 #define PAGK_PRIO_MODE 1
-#endif
-#ifndef PAGK_PRIO_K
-#define PAGK_PRIO_K 4
 #endif
 #if PAGK_PRIO_MODE == 0
 #define PAGK_PRIO_DECL
@@ -39,7 +36,7 @@
 // The priority is switched once per transition: two scalar instructions on the path of an iteration without one.
 #define PAGK_PRIO_TIER                                                                                              \
     {                                                                                                               \
-        const int tier = (kPrioByWork && __builtin_amdgcn_readfirstlane(iters - PAGK_PRIO_K * (a.n_levels - level)) > 0) ? 3 : 0; \
+        const int tier = (kPrioByWork && a.prio_k > 0 && __builtin_amdgcn_readfirstlane(iters - a.prio_k * (a.n_levels - level)) > 0) ? 3 : 0; \
         asm volatile("s_cmp_eq_u32 %0, %1\n\t"                                                                      \
                      "s_cbranch_scc1 2f\n\t"                                                                        \
                      "s_cmp_eq_u32 %1, 0\n\t"                                                                       \

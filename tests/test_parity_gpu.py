@@ -360,6 +360,26 @@ def test_baseline_configs_against_oracle(ctx, idx, n):
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("k", [0, 1, 9])
+def test_the_priority_threshold_changes_no_bit(monkeypatch, k):
+    # csrc/pagk_prio.h: a 4-wave workgroup past K iterations per pyramid level entered runs at issue priority 3 (PAGK_PRIO_K; the
+    # product's 4 runs in every other test).  0 = nobody, 1 = nearly everybody from the second iteration, 9 = almost nobody:
+    # s_setprio moves no arithmetic, so each setting is the oracle's bits -- pipelined body (h = 10, crowded CUs), serial body
+    # with three sampling rounds (h = 12) and the five-workgroups-per-CU build (2600 features)
+    monkeypatch.setenv("PAGK_PRIO_K", str(k))
+    c = capi.Context(0)
+    try:
+        for w in (synth.config(1, n=1000), synth.config(1, n=2600),
+                  synth.make_workload("h12", 320, 240, 600, seed=0x5EED0300 + k, half_patch=12, iterations=20, pyramids=3, camera=synth.D435I)):
+            p = params_for(w)
+            ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+            got = c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+            assert c.last_variant() == 0
+            assert_parity(got, ref, w.n, exact=True, what=f"{w.name} PAGK_PRIO_K={k}")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n", [1100, 1280, 1281, 2600])
 def test_launch_sizes_around_the_five_workgroups_per_cu_window(ctx, n):
     # automatic selection at h = 10: the pipelined 4-wave kernel up to 4 workgroups per CU, its five-per-CU build for what
