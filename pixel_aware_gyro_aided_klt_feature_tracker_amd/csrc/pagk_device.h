@@ -102,9 +102,6 @@ struct TrackArgs {
     int batch_k;
     int half, iterations;
     int prio_k;  // pagk_prio.h: a 4-wave workgroup past prio_k iterations per level entered is behind (0: never)
-    // ... or, when non-null, the threshold follows the workload: [0] iterations and [1] feature-levels this context's 4-wave launches have
-    // run so far (device memory, cumulative, seeded with the BASELINE mean); K = ceil([0] / [1]) in 3..12, read once per workgroup
-    unsigned long long *prio_stats;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

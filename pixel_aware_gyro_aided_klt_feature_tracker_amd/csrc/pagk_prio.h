@@ -4,8 +4,7 @@
 // iteration of every one of them is stretched from 6.1 k to 10.6 k cycles: the feature that
 // will need 26 iterations pays for the company of three that need 10.  Which feature that is cannot be known in
 // advance, but it shows: all workgroups of a launch start together and iterate at the same pace, so one that has used
-// more iterations than K (prio_threshold() below: the workload's own mean rounded up, 4 on the BASELINE configs; PAGK_PRIO_K in the
-// environment of pagk_create fixes it, 0 = off) per pyramid level it has entered is BEHIND its neighbours and has the most work
+// more iterations than K (TrackArgs::prio_k: 4, PAGK_PRIO_K in the environment of pagk_create, 0 = off) per pyramid level it has entered is BEHIND its neighbours and has the most work
 // left.  Longest-remaining-work-first is the makespan rule: a workgroup that is behind runs every phase at priority 3,
 // the others keep the by-phase priorities below it (ordered chains 2, second sampling round 1, cost chain 1, the rest
 // 0) and lose only issue slots they had slack for.  K = 4: the mean of the BASELINE workloads is 3.5 iterations per
@@ -19,34 +18,6 @@
 #ifndef PAGK_PRIO_MODE
 #define PAGK_PRIO_MODE 1
 #endif
-
-namespace pagk {
-// K of this launch: the fixed one (TrackArgs::prio_k; PAGK_PRIO_K in the environment), or -- the default -- the mean number of
-// iterations per feature and level that this context's launches have run so far, rounded up: the threshold sits just above what
-// an ordinary feature needs, whatever the imagery (3.5 on the BASELINE workloads: K = 4, the value the sweeps chose).  Two plain
-// loads per workgroup, before its first level; the counters are fed by prio_account() below with fire-and-forget atomics.
-__device__ __forceinline__ int prio_threshold(const TrackArgs &a)
-{
-    int k = a.prio_k;
-    if (a.prio_stats) {
-        const unsigned long long it = a.prio_stats[0], lv = a.prio_stats[1];
-        if (lv > 0) {
-            k = (int)ceilf((float)it / (float)lv);
-            k = k < 3 ? 3 : (k > 12 ? 12 : k);
-        }
-    }
-    return __builtin_amdgcn_readfirstlane(k);
-}
-// one lane per feature, once, when the feature has run all its levels in ONE body (a resumed feature was counted by nobody: its
-// first levels ran in another kernel)
-__device__ __forceinline__ void prio_account(const TrackArgs &a, int iters, int levels)
-{
-    if (a.prio_stats) {
-        __hip_atomic_fetch_add(a.prio_stats + 0, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.prio_stats + 1, (unsigned long long)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-}  // namespace pagk
 #if PAGK_PRIO_MODE == 0
 #define PAGK_PRIO_DECL
 #define PAGK_PRIO_TIER
@@ -57,9 +28,7 @@ __device__ __forceinline__ void prio_account(const TrackArgs &a, int iters, int 
 #define PAGK_PRIO_N_COST 1
 #define PAGK_PRIO_N_REST 0
 #else
-#define PAGK_PRIO_DECL   \
-    int tier_now = 0;    \
-    const int prio_k = kPrioByWork ? pagk::prio_threshold(a) : 0;
+#define PAGK_PRIO_DECL int tier_now = 0;
 #define PAGK_STR2(x) #x
 #define PAGK_STR(x) PAGK_STR2(x)
 // (wave-uniform: iters, level and the kernel argument are the same in every lane; readfirstlane says so to the compiler, and
@@ -67,7 +36,7 @@ __device__ __forceinline__ void prio_account(const TrackArgs &a, int iters, int 
 // The priority is switched once per transition: two scalar instructions on the path of an iteration without one.
 #define PAGK_PRIO_TIER                                                                                              \
     {                                                                                                               \
-        const int tier = (prio_k > 0 && __builtin_amdgcn_readfirstlane(iters - prio_k * (a.n_levels - level)) > 0) ? 3 : 0; \
+        const int tier = (kPrioByWork && a.prio_k > 0 && __builtin_amdgcn_readfirstlane(iters - a.prio_k * (a.n_levels - level)) > 0) ? 3 : 0; \
         asm volatile("s_cmp_eq_u32 %0, %1\n\t"                                                                      \
                      "s_cbranch_scc1 2f\n\t"                                                                        \
                      "s_cmp_eq_u32 %1, 0\n\t"                                                                       \
