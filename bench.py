@@ -30,6 +30,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (before torch or anything else can initialise the HIP runtime: the package sets its process-level runtime defaults on import)
+from pixel_aware_gyro_aided_klt_feature_tracker_amd import runtime_env  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NOMINAL_N = {0: 500, 1: 1000, 2: 2000, 3: 20000, 4: 4000}   # keypoints BASELINE.json quotes per config
@@ -512,6 +514,7 @@ def main() -> int:
             "per_gpu_ms_per_step": per_gpu_ms,
             "ms_per_step_cold": elapsed_cold / args.steps * 1e3, "value_cold": n_active_total * args.steps / elapsed_cold,
             "dtype": "f32 sampling, f64 normal equations", "data": "synthetic", "spinup_s": spinup_s,
+            "runtime_env": runtime_env.IN_FORCE,
             "config": {"workload": f"{w.name}: {w.img_ref.shape[1]}x{w.img_ref.shape[0]} pair, "
                                    f"{n_total * world if replicas else n_total} keypoints "
                                    f"({per_gpu if replicas or args.scaling != 'strong' else n_total // world}/GPU), "
