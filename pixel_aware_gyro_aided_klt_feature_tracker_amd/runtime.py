@@ -192,7 +192,9 @@ class ResidentTracker:
           "fork"    that overlap as two branches of one graph: 143.6 us;
           "fused"   the next frame's pyramid as trailing workgroups of the tracking launch itself
                     (pagk_track_device_fused), one single-node graph per parity: the pyramid costs no launch and no
-                    gap.  Like "streams" it needs frame k+1 while pair (k-1, k) is tracked."""
+                    gap.  Like "streams" it needs frame k+1 while pair (k-1, k) is tracked.
+        What comes back without a collective is plain VIEWS of the tracker's output buffers, written by launches on `main`:
+        read them after synchronize() or on `main` (a Gathered, from the sharded step, orders its reader by itself)."""
         gather = gather and not mode.endswith("-nogather")
         mode = mode.replace("-nogather", "")
         graph = {"graph": True, "fork": "fork", "fused": "fused"}.get(mode, False)

@@ -68,8 +68,9 @@ def test_runtime_gathers_through_the_c_abi_communicator(built):
     refs = []
     for f in frames:
         plain.set_current_image(f)
-        refs.append(distributed.to_numpy(plain.step()))
-        plain.synchronize()
+        res = plain.step()
+        plain.synchronize()   # (an ungathered result is plain views of the tracker's buffers: read them behind ITS stream --
+        refs.append(distributed.to_numpy(res))   # reading first raced with the step whenever the two streams sat on different HW queues)
     assert not np.array_equal(refs[0]["pt_un"], refs[1]["pt_un"])
     distributed.COMM, distributed.FORCE_COLLECTIVE = g, True
     gots = []
