@@ -4,6 +4,8 @@
 set -o pipefail
 TAG=${1:-r01}
 export TMPDIR=/tmp
+# the package's process-level runtime default (runtime_env.py) -- exported here because the profiler's preloaded library initialises HIP before python starts
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=${DEBUG_CLR_GRAPH_PACKET_CAPTURE:-0}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
