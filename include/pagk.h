@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PAGK_VERSION 302 /* 0.3.2: + pagk_frame_set_device_batch; 0.3.1: pipelined 4-wave kernel, pagk_track_device_batch, pagk_check_launch, pagk_selftest_repeat_sum */
+#define PAGK_VERSION 303 /* 0.3.3: + pagk_priority_threshold; 0.3.2: + pagk_frame_set_device_batch; 0.3.1: pipelined 4-wave kernel, pagk_track_device_batch, pagk_check_launch, pagk_selftest_repeat_sum */
 
 #define PAGK_MAX_PYRAMIDS 8
 #define PAGK_MAX_HALF_PATCH 15 /* (2h+1)^2 <= 961 pixels */
@@ -249,6 +249,12 @@ int pagk_last_variant(const pagk_ctx *ctx);
 /* Number of features the last tracking launch of this context handed from the throughput kernel to the latency
  * kernel (variant 5, see above); 0 when the launch did not use the hand-over.  Synchronises the context's stream. */
 int pagk_last_handover(pagk_ctx *ctx);
+
+/* Diagnostic: the threshold K the next launch of the 4-wave kernels will use for its issue priorities (a workgroup that has used more
+ * than K iterations per pyramid level entered outranks its neighbours; csrc/pagk_prio.h -- no arithmetic effect).  4 by default;
+ * PAGK_PRIO_K in the environment of pagk_create fixes another value (0 = off) or, as "auto", lets K follow the mean number of
+ * iterations per feature and level the context's launches have run.  No counterpart in the reference.  Synchronises the context's stream. */
+int pagk_priority_threshold(pagk_ctx *ctx);
 
 /* Concurrency hint for the automatic selection: the caller runs `streams` contexts like this one at the same time on
  * this device (one PatchMatch per camera stream, BASELINE configs[4]: src/patch_match.cpp:79-142 called from several

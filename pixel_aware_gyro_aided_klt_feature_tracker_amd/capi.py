@@ -214,6 +214,9 @@ def declare(lib) -> None:
         lib.pagk_selftest_divide.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         lib.pagk_selftest_solve.restype = C.c_int
         lib.pagk_selftest_solve.argtypes = [vp, i32, vp, vp, C.c_uint32, vp, vp, vp, vp]
+    if hasattr(lib, "pagk_priority_threshold"):
+        lib.pagk_priority_threshold.restype = C.c_int
+        lib.pagk_priority_threshold.argtypes = [vp]
     if hasattr(lib, "pagk_check_launch"):
         lib.pagk_check_launch.restype = C.c_int
         lib.pagk_check_launch.argtypes = [vp]
@@ -264,7 +267,7 @@ EXPORTED_SYMBOLS = [
     "pagk_multi_create", "pagk_multi_unique_id", "pagk_multi_create_rank", "pagk_multi_destroy", "pagk_multi_world",
     "pagk_multi_local", "pagk_multi_ctx", "pagk_multi_last_error", "pagk_shard_range", "pagk_shard_layout",
     "pagk_multi_allgather", "pagk_track_sharded", "pagk_selftest_divide", "pagk_selftest_solve",
-    "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch", "pagk_frame_set_device_batch",
+    "pagk_selftest_repeat_sum", "pagk_check_launch", "pagk_track_device_batch", "pagk_frame_set_device_batch", "pagk_priority_threshold",
     "pagk_multi_comm_count", "pagk_has_variant",
 ]
 
@@ -587,6 +590,13 @@ class Context:
                      4: "relaxed order (experiment)", 5: "four features per wave, f64 MFMA blocks",
                      6: "four independent rows per wave + work queue",
                      7: "four features per wave, one pyramid level per wave"}
+
+    def priority_threshold(self) -> int:
+        """K of the next 4-wave launch's issue priorities (csrc/pagk_prio.h); synchronises."""
+        rc = int(self.lib.pagk_priority_threshold(self.h))
+        if rc < 0:
+            self._check(rc, "pagk_priority_threshold")
+        return rc
 
     def last_variant(self) -> int:
         return int(self.lib.pagk_last_variant(self.h))

@@ -102,6 +102,11 @@ struct TrackArgs {
     int batch_k;
     int half, iterations;
     int prio_k;  // pagk_prio.h: a 4-wave workgroup past prio_k iterations per level entered is behind (0: never)
+    // PAGK_PRIO_K=auto: the threshold follows the workload.  prio_stats[0] / [1] = iterations / feature-levels this context's 4-wave
+    // launches have run (device memory, cumulative, seeded with the BASELINE mean), prio_kbuf = ceil of their ratio in 3..12, refreshed by the
+    // workgroups that finish early and read -- one load, consumed a level set-up later -- by every workgroup of the NEXT launches
+    unsigned long long *prio_stats;
+    const int *prio_kbuf;
     int has_gyro, illum, use_affine, penalty, calc_ncc;
     uint32_t solver;        // pagk_params::solver_variant (SV_* bits)
     float lam_invlog;       // mLambda * mInvLogMaxDist            (f32 product, :305)

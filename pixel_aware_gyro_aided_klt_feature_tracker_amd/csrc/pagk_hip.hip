@@ -127,6 +127,7 @@ struct pagk_ctx {
     int quad_min_features = 7000;        // PAGK_QUAD_MIN: four features per wave (pagk_quad_kernel.h)
     int block5_min_features = 2500;      // PAGK_BLOCK5_MIN: the 4-wave kernel in its five-workgroups-per-CU build (h = 10)
     int prio_k = 4;                      // PAGK_PRIO_K: iterations per pyramid level beyond which a 4-wave workgroup counts as behind (pagk_prio.h); 0 = rule off
+    unsigned long long *prio_stats = nullptr;  // PAGK_PRIO_K=auto: device block [iterations, feature-levels (u64 each), K (int)]
     bool block5_window = true;           // ... also for launches that only five workgroups per CU hold in one round (off when PAGK_BLOCK5_MIN is set)
     int levels_min_features = 6000;      // PAGK_LEVELS_MIN: ... one level per wave (a context alone on the device)
     int levels_shift = 0;                // PAGK_LEVELS_XCD_SHIFT (tests): waves start with another XCD's ticket sequence
@@ -583,6 +584,8 @@ int launch_track(pagk_ctx *ctx, const pagk_params *p, const FrameSlot &sr, const
 #endif
     fill_param_args(a, p);
     a.prio_k = ctx->prio_k;
+    a.prio_stats = ctx->prio_stats;
+    a.prio_kbuf = ctx->prio_stats ? reinterpret_cast<const int *>(ctx->prio_stats + 2) : nullptr;
 
     if (ctx->ev_trk[0] && !in_capture(ctx)) HIPCHK(ctx, hipEventRecord(ctx->ev_trk[0], ctx->stream));
     if (n > 0) {
@@ -1137,7 +1140,18 @@ int pagk_create(pagk_ctx **out, int device)
     if (getenv("PAGK_QUAD_MIN")) ctx->quad_min_features = atoi(getenv("PAGK_QUAD_MIN"));
     if (getenv("PAGK_BLOCK5_MIN")) ctx->block5_min_features = atoi(getenv("PAGK_BLOCK5_MIN")), ctx->block5_window = false;
     if (getenv("PAGK_LEVELS_MIN")) ctx->levels_min_features = atoi(getenv("PAGK_LEVELS_MIN"));
-    if (getenv("PAGK_PRIO_K")) ctx->prio_k = atoi(getenv("PAGK_PRIO_K")) < 0 ? 0 : atoi(getenv("PAGK_PRIO_K"));
+    if (getenv("PAGK_PRIO_K") && strcmp(getenv("PAGK_PRIO_K"), "auto") == 0) {
+        // seeded with the BASELINE workloads' mean (3.5 iterations per feature and level: K = 4 until the context's own launches say otherwise)
+        struct { unsigned long long st[2]; int k, pad; } seed = {{3500ull, 1000ull}, ctx->prio_k, 0};
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->prio_stats), sizeof seed) != hipSuccess ||
+            hipMemcpy(ctx->prio_stats, &seed, sizeof seed, hipMemcpyHostToDevice) != hipSuccess) {
+            if (ctx->prio_stats) (void)hipFree(ctx->prio_stats);
+            ctx->prio_stats = nullptr;   // (the fixed threshold then)
+            (void)hipGetLastError();
+        }
+    } else if (getenv("PAGK_PRIO_K")) {
+        ctx->prio_k = atoi(getenv("PAGK_PRIO_K")) < 0 ? 0 : atoi(getenv("PAGK_PRIO_K"));
+    }
     if (getenv("PAGK_LEVELS_XCD_SHIFT")) ctx->levels_shift = atoi(getenv("PAGK_LEVELS_XCD_SHIFT")) & 7;
     if (getenv("PAGK_LEVELS_SHARED")) ctx->levels_shared = atoi(getenv("PAGK_LEVELS_SHARED")) != 0;
     if (getenv("PAGK_QUAD_BUDGET")) ctx->quad_budget = atoi(getenv("PAGK_QUAD_BUDGET"));
@@ -1191,6 +1205,7 @@ void pagk_destroy(pagk_ctx *ctx)
     if (ctx->susp) (void)hipFree(ctx->susp);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->lv) (void)hipFree(ctx->lv);
+    if (ctx->prio_stats) (void)hipFree(ctx->prio_stats);
     for (auto &d : ctx->batch_ring) batch_desc_free(d);
     batch_desc_free(ctx->cap_batch);
     for (int k = 0; k < pagk_ctx::kGraphs; k++) batch_desc_free(ctx->graph_batch[k]);
@@ -1248,6 +1263,19 @@ int pagk_last_handover(pagk_ctx *ctx)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (int lr = lv_check(ctx)) return lr;
     return count;
+}
+
+// The K the next launch of the 4-wave kernels will use (csrc/pagk_prio.h): the fixed one, or what the context's statistics say.
+int pagk_priority_threshold(pagk_ctx *ctx)
+{
+    if (!ctx) return PAGK_E_ARG;
+    if (!ctx->prio_stats) return ctx->prio_k;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int k = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&k, ctx->prio_stats + 2, sizeof k, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int lr = lv_check(ctx)) return lr;
+    return k;
 }
 
 // The error word of the level-by-level launches without a synchronisation: for callers that synchronise the stream

@@ -493,6 +493,7 @@ __device__ __forceinline__ void track_pipe_body(const TrackArgs &a, const int i,
         ncc = (float)((double)sh_f[2] / sqrt((double)(sh_f[3] * sh_f[4]) + 1e-10));
     }
     if (tid == 0) write_outputs(a, i, p2x, p2y, succ, lastCost, 1, ncc, iters);
+    if (tid == 0 && kPrioByWork && !resume) prio_account(a, i, iters, a.n_levels);
 #ifdef PAGK_STAMPS
     if (lane == 0 && a.dbg) {
         // resumed features: after the throughput kernel's per-wave records

@@ -55,7 +55,7 @@ def test_c_program_drives_the_library_on_the_device(built, tmp_path):
 
 def test_version_errors_defaults(built):
     lib = capi.load()
-    assert lib.pagk_version() == 302
+    assert lib.pagk_version() == 303
     assert lib.pagk_strerror(0) == b"ok" and lib.pagk_strerror(-4) == b"unsupported mode"
     p = capi.Params()
     lib.pagk_params_default(C.byref(p))

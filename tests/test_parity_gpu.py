@@ -380,6 +380,40 @@ def test_the_priority_threshold_changes_no_bit(monkeypatch, k):
         c.close()
 
 
+def test_the_priority_threshold_can_follow_the_workload(monkeypatch):
+    # PAGK_PRIO_K=auto: K = the context's own mean iterations per feature and level, rounded up, in 3..12 (device-side counters fed
+    # by the 4-wave kernels, refreshed by the features that finish early; csrc/pagk_prio.h).  A fresh context starts from the
+    # BASELINE mean (K = 4) and stays there on configs[1]; a workload whose features all stop at a one-iteration limit pulls it
+    # to the floor; results are the oracle's throughout.  Without the variable K is the fixed 4.
+    c0 = capi.Context(0)
+    try:
+        assert c0.priority_threshold() == 4
+    finally:
+        c0.close()
+    monkeypatch.setenv("PAGK_PRIO_K", "auto")
+    c = capi.Context(0)
+    try:
+        assert c.priority_threshold() == 4
+        w = synth.config(1, n=1000)
+        p = params_for(w)
+        ref = orc.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in, nthreads=16)
+        for _ in range(3):
+            got = c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert_parity(got, ref, w.n, exact=True, what="configs[1], PAGK_PRIO_K=auto")
+        assert c.priority_threshold() == 4          # 3.5 iterations per feature and level
+        w1 = synth.make_workload("one_iteration", 320, 240, 900, seed=0x5EED0400, half_patch=10, iterations=1, pyramids=3, camera=synth.D435I)
+        p1 = params_for(w1)
+        ref1 = orc.track(p1, w1.img_ref, w1.img_cur, w1.pt_ref, w1.pt_init, w1.affine, w1.status_in, nthreads=16)
+        for _ in range(12):
+            got1 = c.track(p1, w1.img_ref, w1.img_cur, w1.pt_ref, w1.pt_init, w1.affine, w1.status_in)
+        assert_parity(got1, ref1, w1.n, exact=True, what="one iteration per level")
+        assert c.priority_threshold() == 3          # mean -> 1: the floor
+        got = c.track(p, w.img_ref, w.img_cur, w.pt_ref, w.pt_init, w.affine, w.status_in)
+        assert_parity(got, ref, w.n, exact=True, what="configs[1] at K = 3")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n", [1100, 1280, 1281, 2600])
 def test_launch_sizes_around_the_five_workgroups_per_cu_window(ctx, n):
     # automatic selection at h = 10: the pipelined 4-wave kernel up to 4 workgroups per CU, its five-per-CU build for what

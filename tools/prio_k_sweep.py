@@ -19,7 +19,7 @@ for cfg, n, L in ((1, 250, 3), (1, 1000, 3), (1, 2000, 3), (2, 2000, 4)):
 print("   ".join(out))
 '''
 for rep in range(2):
-    for k in ("0", "3", "4", "5"):
+    for k in os.environ.get("PAGK_K_LIST", "0,3,4,5").split(","):
         e = dict(os.environ); e["PAGK_PRIO_K"] = k; e["PAGK_ROOT"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=e)
         print("PAGK_PRIO_K=" + k, "|", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
